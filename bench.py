@@ -1,0 +1,213 @@
+"""bench.py - NGCF 3-layer forward on MI355X: propagated edges/s + roofline of the SpMM kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2..3]): synthetic bipartite graph, 1 M users x 100 K items,
+50 M drawn interactions (popularity-skewed items, de-duplicated; the actual count is reported), both triangles
+stored -> nnz(L) = 2 x interactions; d0 = d = 128, 3 layers, fp32, random-init weights, batch of 1024 triplets.
+One "step" = one pass of the hot path: E0 -> 3 x (L.E SpMM + fused dense/LeakyReLU/normalise) -> all_E,
+3 row gathers, fused BPR loss  (NGCF.py:120-156 + bprloss.py:15-22).  The feature injection (NGCF.py:103-115)
+is not part of the step at this width: the reference itself raises for embed_size = 128 (not a multiple of 5).
+Unit of work: one stored nonzero of L processed in one layer; value = n_layers * nnz(L) * steps / time.
+N > 1: the SAME graph is row-partitioned over the ranks (strong scaling), exchange scheme `--exchange`.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (n_user, n_item, interactions, d0, layers, seed)
+    "c3": (1_000_000, 100_000, 50_000_000, 128, (128, 128, 128), 2603),
+    "c5": (10_000_000, 1_000_000, 500_000_000, 256, (256, 256, 256), 2605),
+    "small": (100_000, 10_000, 2_000_000, 128, (128, 128, 128), 2603),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--exchange", default="bipartite", choices=["bipartite", "allgather"])
+    ap.add_argument("--seg-len", type=int, default=0, help="override the row-segment length (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--uniform-items", action="store_true", help="secondary line: no popularity skew")
+    return ap.parse_args()
+
+
+def spmm_model_a_bytes(nnz, n_rows, n_cols, d):
+    """Compulsory traffic of one SpMM launch (SURVEY.md 8d model A): CSR once, E read once, LE written once."""
+    return nnz * 8 + (n_rows + 1) * 8 + n_cols * d * 4 + n_rows * d * 4
+
+
+def cpu_baseline(coo, model, n_threads):
+    """The reference's PyTorch CPU path (oracle/ngcf_oracle.py, bit-exact restatement) on a bounded sample:
+    ONE propagation layer (layer 1 of 3) of the same graph and weights, on this node's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ngcf_oracle as orc
+    N = coo["n_user"] + coo["n_item"]
+    idx = torch.stack([coo["rows"], coo["cols"]]).cpu()
+    L = torch.sparse_coo_tensor(idx, coo["vals"].cpu(), (N, N))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(n_threads)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], [sd["w1_list.0.weight"]],
+                            [sd["w1_list.0.bias"]], [sd["w2_list.0.weight"]], [sd["w2_list.0.bias"]])
+    dt = time.perf_counter() - t0
+    return {"value": coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
+            "sample": f"1 of 3 layers (SpMM + 3 Linear + LeakyReLU + normalize + cat) of the same graph, "
+                      f"nnz(L)={coo['nnz']}, d=128, torch {torch.__version__} CPU, {dt:.1f} s, single run",
+            "seconds": dt}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import seoul_tourism_recommendation_ngcf_amd as pkg
+    from seoul_tourism_recommendation_ngcf_amd import _lib, dist as ngcf_dist
+    lib = _lib.load()
+
+    n_user, n_item, n_inter, d0, layers, seed = WORKLOADS[args.workload]
+    coo = pkg.graphs.synthetic_bipartite(n_user, n_item, n_inter, seed=seed, device=dev,
+                                         item_skew=not args.uniform_items)
+    nnz, N = coo["nnz"], n_user + n_item
+    num_dict = {"user": n_user, "item": n_item, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(seed)                                   # same parameters on every rank
+    lap = pkg.graphs.to_sparse_coo(coo) if world == 1 else None
+    model = pkg.NGCF(d0, list(layers), None, None, 1.0, [lap], num_dict, args.batch, dev).to(dev).eval()
+    model.check_indices = False                               # ids are generated in range; no host sync per step
+    crit = pkg.BPR(0.025, args.batch)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    u_id = torch.randint(0, n_user, (args.batch,), generator=g).to(dev)
+    pos = torch.randint(0, n_item, (args.batch,), generator=g).to(dev)
+    neg = torch.randint(0, n_item, (args.batch,), generator=g).to(dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    if world == 1:
+        csr = model.laplacian_csr(0)
+        if args.seg_len:
+            csr.plan(args.seg_len)
+        local_nnz = csr.nnz
+        spmm_shapes = [(csr.nnz, csr.n_rows, csr.n_cols)]
+
+        def step():
+            model.propagate(0)
+            u = pkg.engine.gather_rows(model.all_users_emb, u_id, status)
+            p = pkg.engine.gather_rows(model.all_items_emb, pos, status)
+            n = pkg.engine.gather_rows(model.all_items_emb, neg, status)
+            return crit(u, p, n)
+    else:
+        sh = ngcf_dist.ShardedPropagation(model, coo["rows"], coo["cols"], coo["vals"], mode=args.exchange)
+        local_nnz = sh.local_nnz
+        if args.exchange == "bipartite":
+            spmm_shapes = [(sh.csr_it.nnz, sh.csr_it.n_rows, sh.csr_it.n_cols), (sh.csr_u.nnz, sh.csr_u.n_rows, sh.csr_u.n_cols)]
+        else:
+            spmm_shapes = [(sh.csr_i.nnz, sh.csr_i.n_rows, sh.csr_i.n_cols), (sh.csr_u.nnz, sh.csr_u.n_rows, sh.csr_u.n_cols)]
+        if args.seg_len:
+            for c in (sh.csr_u, getattr(sh, "csr_it", None), getattr(sh, "csr_i", None)):
+                if c is not None:
+                    c.plan(args.seg_len)
+
+        def step():
+            sh.propagate()
+            u, p, n = sh.gather(u_id, pos, neg)
+            return crit(u, p, n)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    lib.ngcf_prof_enable(1)                                   # hipEvent pair around every SpMM launch
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    import ctypes as C
+    n_launch, spmm_ms = C.c_int64(), C.c_double()
+    _lib.check(lib.ngcf_prof_collect(C.byref(n_launch), C.byref(spmm_ms)))
+    lib.ngcf_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "non-finite loss"
+
+    n_layer = len(layers)
+    edges_per_step = n_layer * nnz                            # whole job, all ranks
+    value = edges_per_step * args.steps / dt
+    # roofline of the dominant kernel (spmm_kernel), this rank: algorithmic bytes per launch / mean duration
+    per_launch = sum(spmm_model_a_bytes(z, r_, c_, d0) for z, r_, c_ in spmm_shapes) / len(spmm_shapes)
+    mean_ms = spmm_ms.value / max(n_launch.value, 1)
+    achieved = per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")    # PMC-measured HBM bytes per launch (rocprofv3 --pmc)
+    if os.path.exists(tpath) and world == 1:
+        rec = json.load(open(tpath)).get(args.workload + ("_uniform" if args.uniform_items else ""))
+        if rec and rec.get("seg_len", 0) == (args.seg_len or rec.get("seg_len", 0)):
+            traffic = rec["hbm_bytes_per_spmm_launch"]
+
+    out = {
+        "metric": "NGCF 3-layer forward: propagated edges/sec + achieved HBM GB/s, d=128",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: synthetic bipartite {n_user} users x {n_item} items, "
+                               f"{coo['interactions']} interactions, nnz(L)={nnz}, d0={d0}, layers={list(layers)}, "
+                               f"batch={args.batch}, seed={seed}" + (", uniform items" if args.uniform_items else ""),
+                   "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
+                   "d": d0, "n_layers": n_layer, "batch": args.batch,
+                   "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, exchange={args.exchange}"},
+        "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
+                     "mean_launch_ms": mean_ms,
+                     "gather_bytes_per_launch": local_nnz / max(len(spmm_shapes), 1) * d0 * 4 if world > 1 else nnz * d0 * 4},
+        "loss": float(loss),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(coo, model, os.cpu_count() or 1)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/*
+ * ngcf_hip.h - C ABI of libngcf_hip.so, the MI355X (gfx950) NGCF embedding-propagation engine.
+ *
+ * This is the drop-in boundary for ONE path of haesungpyun/seoul_tourism_recommendation_NGCF:
+ * the body of `NGCF.forward` (model/NGCF.py:102-156) and `BPR.forward` (model/bprloss.py:15-22).
+ * The reference is pure Python on top of PyTorch, so "what its FFI would bind" is the set of
+ * tensor ops it issues on that path; each entry point below names the reference lines it replaces.
+ * The Python mirror of the reference's nn.Module surface (seoul_tourism_recommendation_ngcf_amd/
+ * NGCF.py, bprloss.py) calls these through ctypes with `tensor.data_ptr()` and
+ * `torch.cuda.current_stream().cuda_stream`; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.
+ *   - every `const float*` / `float*` / index pointer is a DEVICE pointer owned by the caller
+ *     unless a comment says "host".  The library allocates only ngcf_csr_t objects.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Compute entry points
+ *     are asynchronous on that stream; ngcf_csr_* builders synchronise it once (one-time set-up).
+ *   - return 0 on success, non-zero on error; ngcf_last_error() gives the message (thread-local).
+ *     The Python mirror raises RuntimeError (IndexError for NGCF_ERR_INDEX), like torch does
+ *     at the same call sites in the reference.
+ *   - row-major fp32 matrices with an explicit leading dimension `ld*` in elements.
+ */
+#ifndef NGCF_HIP_H
+#define NGCF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGCF_OK            0
+#define NGCF_ERR_ARG       1   /* bad argument (null pointer, negative size, unsupported width) */
+#define NGCF_ERR_HIP       2   /* a HIP runtime call failed */
+#define NGCF_ERR_INDEX     3   /* an index is out of range (IndexError in the Python mirror) */
+#define NGCF_ERR_WORKSPACE 4   /* caller's workspace is too small */
+
+typedef struct ngcf_csr ngcf_csr_t;
+
+/* ---- library ------------------------------------------------------------------------- */
+const char *ngcf_last_error(void);
+/* "gfx950" - the only architecture the code objects are built for. */
+const char *ngcf_target_arch(void);
+int ngcf_version(void);
+
+/* Timing of the dominant kernel for bench.py's roofline line: while enabled, every SpMM kernel launch is
+ * bracketed by a hipEvent pair on its own stream.  ngcf_prof_collect waits for them and returns the number
+ * of timed launches and their summed duration (ms), then resets the recorder.  Not thread-safe. */
+int ngcf_prof_enable(int on);
+int ngcf_prof_collect(int64_t *n_launches, double *total_ms);
+
+/* ---- Laplacian: COO (the layout of `lap_list[k]`, matrix.py:79-83) -> CSR -------------- */
+/*
+ * Replaces the per-call `self.lap_list[year_idx].to(device)` + COO SpMM set-up (NGCF.py:118,130):
+ * built once per year slice.  `rows/cols` are int64[nnz] (the two rows of `_indices()`), `vals`
+ * fp32[nnz] (`_values()`), all on the device.  Entries need not be coalesced; duplicates are kept
+ * as separate entries, like the reference's CPU `torch.mm` which FMAs each stored entry.
+ * Row-sorted input (what matrix.py emits) is converted on the device; anything else is stably
+ * sorted by row on the host.  `n_rows` x `n_cols` is the shape of this slab: a full Laplacian has
+ * n_rows == n_cols == N; a row slab of a row-partitioned graph has n_rows < n_cols and row ids
+ * relative to the slab.  Columns are stored as int32 (n_cols < 2^31).
+ * Fails with NGCF_ERR_INDEX when a row/col id is out of range.
+ */
+int ngcf_csr_from_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz,
+                      int64_t n_rows, int64_t n_cols, ngcf_csr_t **out, void *stream);
+/* Adopt device CSR arrays (rowptr int64[n_rows+1], colidx int32[nnz], vals fp32[nnz]); they are
+ * borrowed and must outlive the handle. */
+int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx, const float *vals,
+                         int64_t n_rows, int64_t n_cols, int64_t nnz, ngcf_csr_t **out, void *stream);
+/* Re-plan the row segmentation: rows with more than `seg_len` stored entries are cut into
+ * segments of `seg_len` entries whose partial sums are combined in a fixed order (no atomics). */
+int ngcf_csr_plan(ngcf_csr_t *csr, int32_t seg_len, void *stream);
+void ngcf_csr_free(ngcf_csr_t *csr);
+int64_t ngcf_csr_nnz(const ngcf_csr_t *csr);
+int64_t ngcf_csr_n_rows(const ngcf_csr_t *csr);
+int64_t ngcf_csr_n_cols(const ngcf_csr_t *csr);
+int64_t ngcf_csr_n_segments(const ngcf_csr_t *csr);
+/* device pointers of the CSR arrays (for tests / the transposed view) */
+const int64_t *ngcf_csr_rowptr(const ngcf_csr_t *csr);
+const int32_t *ngcf_csr_colidx(const ngcf_csr_t *csr);
+const float *ngcf_csr_vals(const ngcf_csr_t *csr);
+
+/* ---- propagation ----------------------------------------------------------------------- */
+/* Bytes of workspace ngcf_spmm_csr_f32 / ngcf_layer_fused_f32 need for this CSR at width d_in
+ * (segment partial sums; for the fused layer also the L.E tile and the packed weights). */
+int64_t ngcf_spmm_workspace_bytes(const ngcf_csr_t *csr, int d);
+int64_t ngcf_layer_workspace_bytes(const ngcf_csr_t *csr, int d_in, int d_out);
+
+/*
+ * LE = L.E  (NGCF.py:130, `torch.mm(L, E)`).
+ * E: [n_cols, d] with leading dimension ldE; LE: [n_rows, d] with ldLE.  fp32 FMA accumulation;
+ * the summation order inside a row differs from the reference's sequential order (tolerance in
+ * tests/test_parity_gpu.py).
+ */
+int ngcf_spmm_csr_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d, float *LE,
+                      int64_t ldLE, void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * One whole propagation layer (NGCF.py:130-146) for the rows of `csr`:
+ *   LE    = L.E_gather                                              NGCF.py:130
+ *   M     = (LE+E_self).W1^T + (LE*E_self).W2^T + (2*b1 + b2)       NGCF.py:131-138 (b1 twice)
+ *   carry = dropout_p(leaky_relu(M, slope))                         NGCF.py:140-142
+ *   norm  = carry / max(||carry||_2, 1e-12)                         NGCF.py:144
+ * E_gather: [n_cols, d_in] table the neighbours are read from; E_self: [n_rows, d_in], the same
+ * rows as the output (E_gather + row_start*ld for a row slab).  W1, W2: [d_out, d_in] row-major
+ * (nn.Linear.weight), b1, b2: [d_out].  `carry` ([n_rows, d_out], may be NULL for the last
+ * layer) feeds the next layer; `norm` is written straight into its column block of all_E
+ * (pointer already offset by the block's first column, leading dimension ldn = ld of all_E),
+ * which removes the reference's `torch.cat` (NGCF.py:147).  drop_p == 0 -> no dropout (eval).
+ */
+int ngcf_layer_fused_f32(const ngcf_csr_t *csr, const float *E_gather, int64_t ldEg,
+                         const float *E_self, int64_t ldEs, int d_in,
+                         const float *W1, const float *b1, const float *W2, const float *b2, int d_out,
+                         float leaky_slope, float drop_p, uint64_t drop_seed,
+                         float *carry, int64_t ldc, float *norm, int64_t ldn,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
+/* The dense half alone (NGCF.py:131-146) on an already computed LE; same arguments as above.
+ * Needs ngcf_dense_workspace_bytes(d_in, d_out) bytes of workspace (packed weights). */
+int64_t ngcf_dense_workspace_bytes(int d_in, int d_out);
+int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *E_self, int64_t ldEs,
+                         int64_t n_rows, int d_in,
+                         const float *W1, const float *b1, const float *W2, const float *b2, int d_out,
+                         float leaky_slope, float drop_p, uint64_t drop_seed,
+                         float *carry, int64_t ldc, float *norm, int64_t ldn,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
+/* dst[r, 0:d] = src[r, 0:d] for r < n_rows (strided copy; writes E0 into its block of all_E,
+ * NGCF.py:120-121 + 147). */
+int ngcf_copy_rows_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int d,
+                       void *stream);
+
+/* ---- feature injection (NGCF.py:103-115) ---------------------------------------------- */
+/*
+ * user_w[u_id[b], :] = user_w[u_id[b], :]*(1-r) + cat(age,sex,month,day,dow rows)[b, :]*r.
+ * tables[5]: device pointers of the five [card, fw] tables in the concat order age, sex, month,
+ * day, dow (NGCF.py:110); idx[5]: the five int64[B] index vectors in the same order; cards[5] their
+ * cardinalities (host).  5*fw must equal d0 (the reference raises RuntimeError otherwise).
+ * Duplicate u_id: the LAST occurrence in the batch wins (what the CPU index_put_ of the reference
+ * does).  `scratch` is int32[n_user], all -1 on entry and on exit.
+ * `status` is a device int32: set non-zero when an index is out of range (rows skipped).
+ */
+int ngcf_feature_inject_f32(float *user_w, int64_t ldu, int64_t n_user, int d0,
+                            const float *const *tables, const int64_t *const *idx, const int64_t *cards,
+                            int fw, const int64_t *u_id, int64_t B, double emb_ratio,
+                            int32_t *scratch, int32_t *status, void *stream);
+
+/* ---- gathers (NGCF.py:151-155) ---------------------------------------------------------- */
+/* out[b, 0:d] = table[(row_off + idx[b]), 0:d], bit-exact copies.  idx must lie in [0, n_idx_rows);
+ * offenders are skipped and *status (device int32) is set non-zero. */
+int ngcf_gather_rows_f32(const float *table, int64_t ld, int d, const int64_t *idx, int64_t B,
+                         int64_t row_off, int64_t n_idx_rows, float *out, int64_t ldo,
+                         int32_t *status, void *stream);
+
+/* ---- BPR (bprloss.py:15-22) ------------------------------------------------------------- */
+/*
+ * loss = (-sum_r logsigmoid(|u_r.p_r| - |u_r.n_r|) + wd*(sum|u|^2 + sum|p|^2 + sum|n|^2)) / batch_size
+ * u: [Bu, D], p: [Bp, D], n: [Bn, D] contiguous; each row count is 1 (broadcast) or R = max.
+ * The squared norms run over each tensor's own rows.  `loss` is one device float.
+ * workspace: ngcf_bpr_workspace_bytes(R) bytes.  Deterministic (fixed-order two-stage reduction).
+ */
+int64_t ngcf_bpr_workspace_bytes(int64_t R);
+int ngcf_bpr_fused_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, const float *n, int64_t Bn,
+                       int D, float weight_decay, float batch_size, float *loss,
+                       void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- multi-GPU row partition (new design; host-only helper) --------------- */
+/*
+ * Cut rows [row_begin, row_end) into `world` contiguous ranges of roughly equal stored-entry
+ * count.  rowptr is a HOST int64[n_rows+1].  bounds is a HOST int64[world+1].
+ */
+int ngcf_shard_plan(const int64_t *rowptr_host, int64_t row_begin, int64_t row_end, int world,
+                    int64_t *bounds_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGCF_HIP_H */

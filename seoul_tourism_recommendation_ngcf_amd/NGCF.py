@@ -1,0 +1,198 @@
+"""`NGCF` - the reference's nn.Module surface, backed by the HIP propagation engine.
+
+Drop-in for `/root/reference/model/NGCF.py:7-156`: same constructor, same keyword `forward`,
+same parameter names/shapes (so the reference's 23 checkpoints load with `strict=True`), same
+externally read attributes (`all_users_emb`, `all_items_emb`, demo.py:233), same in-place
+mutation of `user_embedding.weight` (NGCF.py:114-115).  What differs is where the work runs:
+every tensor op of the forward body is a hand-written gfx950 kernel behind the C ABI in
+`include/ngcf_hip.h`; torch only owns the memory.  There is no CPU path: calling `forward`
+with the module on the CPU raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import engine as _eng
+from .autograd import propagate_with_grad
+
+
+class NGCF(nn.Module):
+    def __init__(self,
+                 embed_size: int,
+                 layer_size: list,
+                 node_dropout: float,
+                 mess_dropout: list,
+                 emb_ratio: float,
+                 lap_list: list,
+                 num_dict: dict,
+                 batch_size: int,
+                 device):
+        super().__init__()
+        self.n_user = num_dict['user']
+        self.n_item = num_dict['item']
+        self.emb_size = embed_size
+        self.weight_size = layer_size
+        self.n_layer = len(self.weight_size)
+        self.batch_size = batch_size
+        self.device = device
+        self.node_dropout = node_dropout
+        self.mess_dropout = mess_dropout
+        self.emb_ratio = emb_ratio
+
+        # registration order fixes the state_dict key order of the reference's checkpoints
+        fw = self.emb_size // 5                                     # NGCF.py:39-43
+        self.month_emb = nn.Embedding(num_dict['month'], fw)
+        self.day_emb = nn.Embedding(num_dict['day'], fw)
+        self.sex_emb = nn.Embedding(num_dict['sex'], fw)
+        self.age_emb = nn.Embedding(num_dict['age'], fw)
+        self.dow_emb = nn.Embedding(num_dict['dayofweek'], fw)
+        self.item_embedding = nn.Embedding(self.n_item, self.emb_size)
+        self.user_embedding = nn.Embedding(self.n_user, self.emb_size)
+
+        self.lap_list = lap_list                                    # borrowed, NGCF.py:52
+        for emb in (self.user_embedding, self.item_embedding, self.age_emb, self.sex_emb,
+                    self.month_emb, self.dow_emb, self.day_emb):    # NGCF.py:58-68
+            nn.init.kaiming_uniform_(emb.weight)
+
+        dims = [self.emb_size] + list(self.weight_size)
+        self.w1_list = nn.Sequential(*[nn.Linear(dims[k], dims[k + 1], bias=True) for k in range(self.n_layer)])
+        self.w2_list = nn.Sequential(*[nn.Linear(dims[k], dims[k + 1], bias=True) for k in range(self.n_layer)])
+        self.node_dropout_list = nn.Sequential(
+            *[nn.Dropout(p=self.node_dropout) for _ in range(self.n_layer if self.node_dropout is not None else 0)])
+        self.mess_dropout_list = nn.Sequential(
+            *[nn.Dropout(p=self.mess_dropout[k]) for k in range(self.n_layer if self.mess_dropout is not None else 0)])
+
+        # engine state (not part of the state_dict)
+        self._csr_cache = {}
+        self._ws = _eng.Workspace()
+        self._carry: List[Optional[torch.Tensor]] = [None, None]
+        self._scratch: Optional[torch.Tensor] = None
+        self._status: Optional[torch.Tensor] = None
+        self.check_indices = True        # raise IndexError on out-of-range ids (one host sync per forward)
+        self.node_dropout_mode = "reference"
+        self.all_users_emb = None
+        self.all_items_emb = None
+
+    # ------------------------------------------------------------------------------------
+    # engine plumbing
+    # ------------------------------------------------------------------------------------
+    def _dev(self) -> torch.device:
+        dev = self.user_embedding.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "NGCF propagation engine: parameters are on '%s'. This module runs hand-written HIP kernels for "
+                "MI355X only and has no CPU fallback; call .to('cuda') first." % dev)
+        return dev
+
+    def _status_buf(self, dev):
+        if self._status is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._status
+
+    def _scratch_buf(self, dev):
+        if self._scratch is None or self._scratch.device != dev or self._scratch.numel() != self.n_user:
+            self._scratch = torch.full((self.n_user,), -1, dtype=torch.int32, device=dev)
+        return self._scratch
+
+    def laplacian_csr(self, year_idx: int) -> "_eng.LaplacianCSR":
+        """CSR of `lap_list[year_idx]`, built once and cached (replaces the per-call `.to(device)`, NGCF.py:118)."""
+        dev = self._dev()
+        L = self.lap_list[year_idx]            # IndexError for a bad year_idx, like the reference
+        key = (year_idx, id(L), str(dev))
+        csr = self._csr_cache.get(key)
+        if csr is None:
+            N = self.n_user + self.n_item
+            if tuple(L.shape) != (N, N):
+                raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(L.shape)} and {N}x{self.emb_size})")
+            csr = _eng.LaplacianCSR.from_sparse_coo(L, dev)
+            self._csr_cache = {k: v for k, v in self._csr_cache.items() if k[0] != year_idx}
+            self._csr_cache[key] = csr
+        return csr
+
+    def _layer_params(self):
+        return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],
+                [l.weight for l in self.w2_list], [l.bias for l in self.w2_list])
+
+    def _dropped_csr_list(self, year_idx: int):
+        """Cumulative, unscaled node dropout of NGCF.py:93-100,124-126 ("reference" mode).
+
+        The keep mask is drawn exactly as the reference does - `nn.Dropout(p)` on float64 ones from the
+        CPU default generator, once per layer on the already thinned matrix - so the kept edge sets are
+        bit-identical for the same `torch.manual_seed`.  Each layer gets its own (smaller) CSR.
+        """
+        dev = self._dev()
+        L = self.lap_list[year_idx]
+        idx = L._indices().to(dev)
+        val = L._values().to(device=dev, dtype=torch.float32)
+        N = self.n_user + self.n_item
+        out = []
+        for _ in range(self.n_layer):
+            mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
+                                               p=self.node_dropout, training=True).type(torch.bool).to(dev)
+            idx, val = idx[:, mask], val[mask]
+            out.append(_eng.LaplacianCSR.from_coo(idx[0], idx[1], val, N, N))
+        return out
+
+    # ------------------------------------------------------------------------------------
+    # propagation (NGCF.py:120-149)
+    # ------------------------------------------------------------------------------------
+    def propagate(self, year_idx: int = 0, node_flag: bool = False) -> torch.Tensor:
+        """all_E = [E0 | norm(E1) | ... | norm(En)]  for the current parameters; sets all_users_emb/all_items_emb."""
+        self._dev()
+        csrs = self._dropped_csr_list(year_idx) if node_flag else [self.laplacian_csr(year_idx)] * self.n_layer
+        drop = [0.0] * self.n_layer
+        if self.training and self.mess_dropout is not None:            # nn.Dropout follows train()/eval(), NGCF.py:142
+            drop = [float(p) for p in self.mess_dropout[:self.n_layer]]
+        seeds = [0] * self.n_layer
+        if any(p > 0 for p in drop):
+            seeds = [int(s) for s in torch.randint(0, 2 ** 62, (self.n_layer,), dtype=torch.int64)]
+        w1, b1, w2, b2 = self._layer_params()
+        all_E = propagate_with_grad(self, csrs, self.user_embedding.weight, self.item_embedding.weight,
+                                    w1, b1, w2, b2, drop, seeds)
+        self.all_users_emb = all_E[:self.n_user, :]                    # NGCF.py:148-149
+        self.all_items_emb = all_E[self.n_user:, :]
+        return all_E
+
+    # ------------------------------------------------------------------------------------
+    # forward (NGCF.py:102-156)
+    # ------------------------------------------------------------------------------------
+    def forward(self, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag):
+        dev = self._dev()
+        status = self._status_buf(dev)
+        fw = self.emb_size // 5
+        if 5 * fw != self.emb_size:
+            # the reference fails at NGCF.py:114 with a shape-mismatch RuntimeError for such widths
+            raise RuntimeError(f"shape mismatch: value tensor of shape [{len(u_id)}, {5 * fw}] cannot be broadcast "
+                               f"to indexing result of shape [{len(u_id)}, {self.emb_size}]")
+        # feature injection into user_embedding.weight.data, no autograd (NGCF.py:103-115)
+        with torch.no_grad():
+            keep = _eng.feature_inject(
+                self.user_embedding.weight.data,
+                (self.age_emb.weight.data, self.sex_emb.weight.data, self.month_emb.weight.data,
+                 self.day_emb.weight.data, self.dow_emb.weight.data),
+                (age, sex, month, day, dow), u_id, self.emb_ratio, self._scratch_buf(dev), status)
+
+        year_idx = int(year.min().item() % 18) if year.numel() else 0   # == year.unique()[0] % 18, NGCF.py:117
+        self.propagate(year_idx, bool(node_flag))
+
+        u_idx = u_id.to(device=dev, dtype=torch.int64)
+        p_idx = pos_item.to(device=dev, dtype=torch.int64)
+        u_embeddings = self._gather(self.all_users_emb, u_idx, status)          # NGCF.py:151
+        pos_i_embeddings = self._gather(self.all_items_emb, p_idx, status)      # NGCF.py:152
+        neg_i_embeddings = torch.empty(0)                                       # NGCF.py:153
+        if len(neg_item) > 0:
+            n_idx = neg_item.to(device=dev, dtype=torch.int64)
+            neg_i_embeddings = self._gather(self.all_items_emb, n_idx, status)  # NGCF.py:155
+        if self.check_indices:
+            if int(status.item()) != 0:
+                status.zero_()
+                raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
+        del keep
+        return u_embeddings, pos_i_embeddings, neg_i_embeddings
+
+    def _gather(self, table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
+        from .autograd import gather_with_grad
+        return gather_with_grad(table, idx, status)

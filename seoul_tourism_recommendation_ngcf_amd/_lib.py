@@ -1,0 +1,98 @@
+"""ctypes binding of libngcf_hip.so (C ABI in include/ngcf_hip.h).
+
+There is no fallback: if the library is missing or fails to load, importing the engine raises.
+torch is imported first so that the library binds to the HIP runtime torch already loaded
+(same SONAME libamdhip64.so.7) - device pointers and streams are then shared.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before libngcf_hip.so, see module docstring)
+
+from . import _build
+
+OK, ERR_ARG, ERR_HIP, ERR_INDEX, ERR_WORKSPACE = 0, 1, 2, 3, 4
+
+_vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/ngcf_hip.h one to one
+PROTOTYPES = {
+    "ngcf_last_error": (C.c_char_p, []),
+    "ngcf_target_arch": (C.c_char_p, []),
+    "ngcf_version": (C.c_int, []),
+    "ngcf_prof_enable": (C.c_int, [C.c_int]),
+    "ngcf_prof_collect": (C.c_int, [C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "ngcf_csr_from_coo": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(_vp), _vp]),
+    "ngcf_csr_from_arrays": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(_vp), _vp]),
+    "ngcf_csr_plan": (C.c_int, [_vp, _i32, _vp]),
+    "ngcf_csr_free": (None, [_vp]),
+    "ngcf_csr_nnz": (_i64, [_vp]),
+    "ngcf_csr_n_rows": (_i64, [_vp]),
+    "ngcf_csr_n_cols": (_i64, [_vp]),
+    "ngcf_csr_n_segments": (_i64, [_vp]),
+    "ngcf_csr_rowptr": (_vp, [_vp]),
+    "ngcf_csr_colidx": (_vp, [_vp]),
+    "ngcf_csr_vals": (_vp, [_vp]),
+    "ngcf_spmm_workspace_bytes": (_i64, [_vp, C.c_int]),
+    "ngcf_layer_workspace_bytes": (_i64, [_vp, C.c_int, C.c_int]),
+    "ngcf_dense_workspace_bytes": (_i64, [C.c_int, C.c_int]),
+    "ngcf_spmm_csr_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
+    "ngcf_layer_fused_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
+                                       _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "ngcf_layer_dense_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
+                                       _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "ngcf_copy_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
+    "ngcf_feature_inject_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
+                                          C.POINTER(_i64), C.c_int, _vp, _i64, C.c_double, _vp, _vp, _vp]),
+    "ngcf_gather_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "ngcf_bpr_workspace_bytes": (_i64, [_i64]),
+    "ngcf_bpr_fused_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp]),
+    "ngcf_shard_plan": (C.c_int, [C.POINTER(_i64), _i64, _i64, C.c_int, C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load libngcf_hip.so (building it first if the sources are newer).  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _build.needs_build():
+        try:
+            _build.build()
+        except Exception as exc:  # noqa: BLE001
+            if not os.path.exists(_build.LIB):
+                raise RuntimeError(
+                    "libngcf_hip.so is not built and could not be built here: " + str(exc)
+                    + "\nThis package has no CPU or PyTorch fallback; run `python __graft_entry__.py build`.") from exc
+    try:
+        lib = C.CDLL(_build.LIB, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise RuntimeError(f"cannot load {_build.LIB}: {exc}; there is no fallback path") from exc
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)        # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ngcf_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    """Translate a non-zero return code into the exception torch raises at the same call site."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == ERR_INDEX:
+        raise IndexError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,1239 @@
+// libngcf_hip.so - NGCF embedding propagation for MI355X (gfx950 / CDNA4).  C ABI: include/ngcf_hip.h
+//
+// Kernels (all fp32, wave = 64 lanes):
+//   spmm / spmm_fixup                    : row-segmented CSR SpMM  LE = L.E          (NGCF.py:130)
+//   pack_weights                         : [W1^T ; W2^T] chunk-interleaved + 2*b1+b2  (NGCF.py:131-138)
+//   layer_dense                          : fp32-MFMA GEMM + bias + LeakyReLU + (dropout) +
+//                                          row L2-normalise, writes carry and all_E block (NGCF.py:131-146)
+//   feature_inject (3 small kernels)     : NGCF.py:103-115
+//   gather_rows                          : NGCF.py:151-155
+//   bpr_rows / bpr_finish                : bprloss.py:15-22
+// gfx950 only: no other architecture, no compatibility paths.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/ngcf_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(NGCF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(NGCF_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+extern "C" const char *ngcf_last_error(void) { return g_err; }
+extern "C" const char *ngcf_target_arch(void) { return "gfx950"; }
+extern "C" int ngcf_version(void) { return 1; }
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// CSR object
+// ---------------------------------------------------------------------------------------------
+struct ngcf_csr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t *rowptr = nullptr;   // device [n_rows+1]
+    int32_t *colidx = nullptr;   // device [nnz]
+    float *vals = nullptr;       // device [nnz]
+    bool owns = false;
+    // row segmentation: rows with > seg_len entries are cut into segments
+    int32_t seg_len = 0;
+    int64_t n_seg = 0, n_heavy = 0;
+    int32_t *seg_row = nullptr;        // device [n_seg]   row of each segment
+    int64_t *seg_begin = nullptr;      // device [n_seg]   first entry of each segment
+    int32_t *heavy_row = nullptr;      // device [n_heavy] rows that were cut
+    int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1] their segment ranges
+};
+
+static const int32_t kDefaultSegLen = 512;
+
+static void free_plan(ngcf_csr *c)
+{
+    if (c->seg_row) (void)hipFree(c->seg_row);
+    if (c->seg_begin) (void)hipFree(c->seg_begin);
+    if (c->heavy_row) (void)hipFree(c->heavy_row);
+    if (c->heavy_seg_ptr) (void)hipFree(c->heavy_seg_ptr);
+    c->seg_row = nullptr;
+    c->seg_begin = nullptr;
+    c->heavy_row = nullptr;
+    c->heavy_seg_ptr = nullptr;
+    c->n_seg = c->n_heavy = 0;
+}
+
+extern "C" void ngcf_csr_free(ngcf_csr_t *c)
+{
+    if (!c) return;
+    free_plan(c);
+    if (c->owns) {
+        if (c->rowptr) (void)hipFree(c->rowptr);
+        if (c->colidx) (void)hipFree(c->colidx);
+        if (c->vals) (void)hipFree(c->vals);
+    }
+    delete c;
+}
+
+extern "C" int64_t ngcf_csr_nnz(const ngcf_csr_t *c) { return c ? c->nnz : -1; }
+extern "C" int64_t ngcf_csr_n_rows(const ngcf_csr_t *c) { return c ? c->n_rows : -1; }
+extern "C" int64_t ngcf_csr_n_cols(const ngcf_csr_t *c) { return c ? c->n_cols : -1; }
+extern "C" int64_t ngcf_csr_n_segments(const ngcf_csr_t *c) { return c ? c->n_seg : -1; }
+extern "C" const int64_t *ngcf_csr_rowptr(const ngcf_csr_t *c) { return c ? c->rowptr : nullptr; }
+extern "C" const int32_t *ngcf_csr_colidx(const ngcf_csr_t *c) { return c ? c->colidx : nullptr; }
+extern "C" const float *ngcf_csr_vals(const ngcf_csr_t *c) { return c ? c->vals : nullptr; }
+
+// flags[0] |= 1 when rows are not non-decreasing; flags[1] |= 1 when an id is out of range
+__global__ void coo_check_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+                                 int64_t nnz, int64_t n_rows, int64_t n_cols, int32_t *flags)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool unsorted = false, bad = false;
+    for (; i < nnz; i += stride) {
+        const int64_t r = rows[i], c = cols[i];
+        bad |= (r < 0) | (r >= n_rows) | (c < 0) | (c >= n_cols);
+        if (i + 1 < nnz) unsorted |= rows[i + 1] < r;
+    }
+    if (unsorted) atomicOr(&flags[0], 1);
+    if (bad) atomicOr(&flags[1], 1);
+}
+
+// rowptr[r] = first entry whose row id is >= r (rows sorted); one thread per r in [0, n_rows]
+__global__ void coo_rowptr_kernel(const int64_t *__restrict__ rows, int64_t nnz, int64_t n_rows,
+                                  int64_t *__restrict__ rowptr)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rows[mid] < r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    rowptr[r] = lo;
+}
+
+__global__ void coo_copy_kernel(const int64_t *__restrict__ cols, const float *__restrict__ vals, int64_t nnz,
+                                int32_t *__restrict__ colidx, float *__restrict__ out_vals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nnz; i += stride) {
+        colidx[i] = (int32_t)cols[i];
+        out_vals[i] = vals[i];
+    }
+}
+
+static int grid_for(int64_t n, int block)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)g;
+}
+
+extern "C" int ngcf_csr_plan(ngcf_csr_t *c, int32_t seg_len, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c) return fail(NGCF_ERR_ARG, "ngcf_csr_plan: null csr");
+    if (seg_len < 64) return fail(NGCF_ERR_ARG, "ngcf_csr_plan: seg_len must be >= 64 (got %d)", seg_len);
+    free_plan(c);
+    c->seg_len = seg_len;
+    std::vector<int64_t> rp((size_t)c->n_rows + 1);
+    HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int32_t> seg_row, heavy_row;
+    std::vector<int64_t> seg_begin, heavy_ptr;
+    heavy_ptr.push_back(0);
+    for (int64_t r = 0; r < c->n_rows; ++r) {
+        const int64_t len = rp[r + 1] - rp[r];
+        if (len > seg_len) {
+            heavy_row.push_back((int32_t)r);
+            for (int64_t b = rp[r]; b < rp[r + 1]; b += seg_len) {
+                seg_row.push_back((int32_t)r);
+                seg_begin.push_back(b);
+            }
+            heavy_ptr.push_back((int64_t)seg_row.size());
+        }
+    }
+    c->n_seg = (int64_t)seg_row.size();
+    c->n_heavy = (int64_t)heavy_row.size();
+    if (c->n_seg > 0) {
+        HIP_TRY(hipMalloc(&c->seg_row, sizeof(int32_t) * seg_row.size()));
+        HIP_TRY(hipMalloc(&c->seg_begin, sizeof(int64_t) * seg_begin.size()));
+        HIP_TRY(hipMalloc(&c->heavy_row, sizeof(int32_t) * heavy_row.size()));
+        HIP_TRY(hipMalloc(&c->heavy_seg_ptr, sizeof(int64_t) * heavy_ptr.size()));
+        HIP_TRY(hipMemcpyAsync(c->seg_row, seg_row.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->seg_begin, seg_begin.data(), sizeof(int64_t) * seg_begin.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->heavy_row, heavy_row.data(), sizeof(int32_t) * heavy_row.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->heavy_seg_ptr, heavy_ptr.data(), sizeof(int64_t) * heavy_ptr.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx, const float *vals,
+                                    int64_t n_rows, int64_t n_cols, int64_t nnz, ngcf_csr_t **out, void *stream)
+{
+    if (!out) return fail(NGCF_ERR_ARG, "ngcf_csr_from_arrays: null out");
+    *out = nullptr;
+    if (!rowptr || (nnz > 0 && (!colidx || !vals)))
+        return fail(NGCF_ERR_ARG, "ngcf_csr_from_arrays: null array");
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_cols >= (int64_t)1 << 31 || n_rows >= (int64_t)1 << 31)
+        return fail(NGCF_ERR_ARG, "ngcf_csr_from_arrays: bad shape %lld x %lld nnz %lld", (long long)n_rows,
+                    (long long)n_cols, (long long)nnz);
+    ngcf_csr *c = new ngcf_csr();
+    c->n_rows = n_rows;
+    c->n_cols = n_cols;
+    c->nnz = nnz;
+    c->rowptr = const_cast<int64_t *>(rowptr);
+    c->colidx = const_cast<int32_t *>(colidx);
+    c->vals = const_cast<float *>(vals);
+    c->owns = false;
+    const int rc = ngcf_csr_plan(c, kDefaultSegLen, stream);
+    if (rc != NGCF_OK) {
+        ngcf_csr_free(c);
+        return rc;
+    }
+    *out = c;
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_csr_from_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz,
+                                 int64_t n_rows, int64_t n_cols, ngcf_csr_t **out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) return fail(NGCF_ERR_ARG, "ngcf_csr_from_coo: null out");
+    *out = nullptr;
+    if (nnz < 0 || n_rows < 0 || n_cols < 0 || n_cols >= (int64_t)1 << 31 || n_rows >= (int64_t)1 << 31)
+        return fail(NGCF_ERR_ARG, "ngcf_csr_from_coo: bad shape %lld x %lld nnz %lld", (long long)n_rows,
+                    (long long)n_cols, (long long)nnz);
+    if (nnz > 0 && (!rows || !cols || !vals)) return fail(NGCF_ERR_ARG, "ngcf_csr_from_coo: null array");
+
+    ngcf_csr *c = new ngcf_csr();
+    c->n_rows = n_rows;
+    c->n_cols = n_cols;
+    c->nnz = nnz;
+    c->owns = true;
+    int32_t *flags = nullptr;
+    int rc = NGCF_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&c->rowptr, sizeof(int64_t) * (size_t)(n_rows + 1)));
+        HIP_TRY(hipMalloc(&c->colidx, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+        HIP_TRY(hipMalloc(&c->vals, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1)));
+        HIP_TRY(hipMalloc(&flags, 2 * sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), stream));
+        int32_t h_flags[2] = {0, 0};
+        if (nnz > 0) {
+            coo_check_kernel<<<grid_for(nnz, 256), 256, 0, stream>>>(rows, cols, nnz, n_rows, n_cols, flags);
+            LAUNCH_CHECK();
+        }
+        HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h_flags[1])
+            return fail(NGCF_ERR_INDEX, "ngcf_csr_from_coo: index out of range for a %lld x %lld matrix",
+                        (long long)n_rows, (long long)n_cols);
+        if (!h_flags[0]) {
+            // rows already sorted (what matrix.py:79-83 emits): convert on the device
+            coo_rowptr_kernel<<<(int)((n_rows + 1 + 255) / 256), 256, 0, stream>>>(rows, nnz, n_rows, c->rowptr);
+            LAUNCH_CHECK();
+            if (nnz > 0) {
+                coo_copy_kernel<<<grid_for(nnz, 256), 256, 0, stream>>>(cols, vals, nnz, c->colidx, c->vals);
+                LAUNCH_CHECK();
+            }
+        } else {
+            // unsorted input: stable sort by row on the host (one-time set-up path)
+            std::vector<int64_t> hr((size_t)nnz), hc((size_t)nnz);
+            std::vector<float> hv((size_t)nnz);
+            HIP_TRY(hipMemcpyAsync(hr.data(), rows, sizeof(int64_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(hc.data(), cols, sizeof(int64_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(hv.data(), vals, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<int64_t> rp((size_t)n_rows + 1, 0);
+            for (int64_t i = 0; i < nnz; ++i) rp[(size_t)hr[i] + 1]++;
+            for (int64_t r = 0; r < n_rows; ++r) rp[(size_t)r + 1] += rp[(size_t)r];
+            std::vector<int64_t> cur(rp.begin(), rp.end() - 1);
+            std::vector<int32_t> oc((size_t)nnz);
+            std::vector<float> ov((size_t)nnz);
+            for (int64_t i = 0; i < nnz; ++i) {   // counting sort = stable
+                const int64_t dst = cur[(size_t)hr[i]]++;
+                oc[(size_t)dst] = (int32_t)hc[i];
+                ov[(size_t)dst] = hv[i];
+            }
+            HIP_TRY(hipMemcpyAsync(c->rowptr, rp.data(), sizeof(int64_t) * rp.size(), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(c->colidx, oc.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(c->vals, ov.data(), sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return ngcf_csr_plan(c, kDefaultSegLen, stream);
+    };
+    rc = body();
+    if (flags) (void)hipFree(flags);
+    if (rc != NGCF_OK) {
+        ngcf_csr_free(c);
+        return rc;
+    }
+    *out = c;
+    return NGCF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMM  LE = L.E   (NGCF.py:130)
+//
+// One wave owns one row (or one <= seg_len-entry segment of a long row).  The wave first reads up
+// to 64 (col, val) pairs with one coalesced load per lane, then walks them: LPR lanes cover one
+// gathered row of E with one 16-byte load each (VEC = 4), so G = 64/LPR neighbour rows are fetched
+// per wave-instruction and U such instructions are kept in flight.  The G lane groups keep
+// private partial sums that are combined with DPP/bpermute shuffles at the end.
+// VEC = 1 is the any-width / any-alignment form (Seoul's d = 65).
+// ---------------------------------------------------------------------------------------------
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+__device__ inline float4 vfma(float s, float4 x, float4 a)
+{
+    a.x = fmaf(s, x.x, a.x);
+    a.y = fmaf(s, x.y, a.y);
+    a.z = fmaf(s, x.z, a.z);
+    a.w = fmaf(s, x.w, a.w);
+    return a;
+}
+__device__ inline float vfma(float s, float x, float a) { return fmaf(s, x, a); }
+__device__ inline float4 vsel(bool p, float4 a, float4 b) { return p ? a : b; }
+__device__ inline float vsel(bool p, float a, float b) { return p ? a : b; }
+__device__ inline float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <int VEC> __device__ inline typename VecT<VEC>::type vzero();
+template <> __device__ inline float4 vzero<4>() { return vzero4(); }
+template <> __device__ inline float vzero<1>() { return 0.f; }
+__device__ inline float4 vshfl_xor(float4 a, int m)
+{
+    a.x = __shfl_xor(a.x, m);
+    a.y = __shfl_xor(a.y, m);
+    a.z = __shfl_xor(a.z, m);
+    a.w = __shfl_xor(a.w, m);
+    return a;
+}
+__device__ inline float vshfl_xor(float a, int m) { return __shfl_xor(a, m); }
+__device__ inline float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ inline float vadd(float a, float b) { return a + b; }
+
+template <int VEC, int LPR, int CH, int U>
+__device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                       int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
+                                       int d, typename VecT<VEC>::type (&acc)[CH])
+{
+    using V = typename VecT<VEC>::type;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPR;
+    const int l = lane % LPR;
+    // column offset of each chunk this lane covers; lanes past the row width read column 0 and
+    // are never written back
+    int coff[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int o = (l + ch * LPR) * VEC;
+        coff[ch] = o < d ? o : 0;
+    }
+    for (int64_t base = begin; base < end; base += 64) {
+        const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+        int c = 0;       // column 0 is always a valid row of E: padding slots read it, masked below
+        float v = 0.f;
+        if (lane < cnt) {
+            c = colidx[base + lane];
+            v = vals[base + lane];
+        }
+        int j = 0;
+        for (; j + G * U <= cnt; j += G * U) {          // full batches: every slot is a real entry
+            V x[U][CH];
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * G + g;
+                const int cc = __shfl(c, idx);
+                vv[u] = __shfl(v, idx);
+                const float *src = E + (int64_t)cc * ldE;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) acc[ch] = vfma(vv[u], x[u][ch], acc[ch]);
+        }
+        if (j < cnt) {                                   // tail batch: slots past cnt are masked
+            V x[U][CH];
+            float vv[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * G + g;
+                ok[u] = idx < cnt;
+                const int cc = __shfl(c, idx & 63);
+                vv[u] = __shfl(v, idx & 63);
+                const float *src = E + (int64_t)cc * ldE;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) acc[ch] = vsel(ok[u], vfma(vv[u], x[u][ch], acc[ch]), acc[ch]);
+        }
+    }
+    // combine the G lane groups
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) acc[ch] = vadd(acc[ch], vshfl_xor(acc[ch], off));
+}
+
+template <int VEC, int LPR, int CH>
+__device__ inline void spmm_store(typename VecT<VEC>::type (&acc)[CH], float *__restrict__ dst, int d)
+{
+    using V = typename VecT<VEC>::type;
+    const int lane = threadIdx.x & 63;
+    if (lane >= LPR) return;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int o = (lane + ch * LPR) * VEC;
+        if (o < d) *reinterpret_cast<V *>(dst + o) = acc[ch];
+    }
+}
+
+// One launch covers the whole product: the first `seg_blocks` workgroups take the segments of the cut
+// rows (the longest units, so they start first; partial sums go to the workspace [n_seg][dp]), the rest
+// take one uncut row per wave and write it directly.  Cut rows are finished by spmm_fixup_kernel.
+template <int VEC, int LPR, int CH, int U>
+__global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ colidx,
+                                                   const float *__restrict__ vals, int64_t n_rows,
+                                                   const int32_t *__restrict__ seg_row,
+                                                   const int64_t *__restrict__ seg_begin, int64_t n_seg,
+                                                   int64_t seg_blocks, int seg_len,
+                                                   const float *__restrict__ E, int64_t ldE, int d,
+                                                   float *__restrict__ out, int64_t ldo,
+                                                   float *__restrict__ partial, int dp)
+{
+    using V = typename VecT<VEC>::type;
+    const int wave = threadIdx.x >> 6;
+    int64_t begin, end;
+    float *dst;
+    if ((int64_t)blockIdx.x < seg_blocks) {
+        const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+        if (s >= n_seg) return;
+        begin = seg_begin[s];
+        const int64_t row_end = rowptr[seg_row[s] + 1];
+        end = begin + seg_len < row_end ? begin + seg_len : row_end;
+        dst = partial + s * (int64_t)dp;
+    } else {
+        const int64_t row = ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
+        if (row >= n_rows) return;
+        begin = rowptr[row];
+        end = rowptr[row + 1];
+        if (end - begin > seg_len) return;   // cut row: produced from its segments
+        dst = out + row * ldo;
+    }
+    V acc[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) acc[ch] = vzero<VEC>();
+    spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc);
+    spmm_store<VEC, LPR, CH>(acc, dst, d);
+}
+
+// cut rows: add their segments' partial sums in segment order (fixed order, no atomics)
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restrict__ heavy_row,
+                                                         const int64_t *__restrict__ heavy_seg_ptr,
+                                                         int64_t n_heavy, const float *__restrict__ partial,
+                                                         int dp, int d, float *__restrict__ out, int64_t ldo)
+{
+    using V = typename VecT<VEC>::type;
+    const int64_t h = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n_heavy) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = heavy_seg_ptr[h], s1 = heavy_seg_ptr[h + 1];
+    float *dst = out + (int64_t)heavy_row[h] * ldo;
+    for (int o = lane * VEC; o < d; o += 64 * VEC) {
+        V acc = vzero<VEC>();
+        for (int64_t s = s0; s < s1; ++s) acc = vadd(acc, *reinterpret_cast<const V *>(partial + s * (int64_t)dp + o));
+        *reinterpret_cast<V *>(dst + o) = acc;
+    }
+}
+
+extern "C" int64_t ngcf_spmm_workspace_bytes(const ngcf_csr_t *c, int d)
+{
+    if (!c || d <= 0) return -1;
+    return align_up(c->n_seg * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optional in-library timing of the dominant kernel (bench.py's roofline figure): when enabled,
+// a hipEvent pair is recorded on the launch stream around every spmm_kernel launch.
+// ---------------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_events;   // pairs: begin, end
+static size_t g_prof_used = 0;
+
+static void prof_mark(hipStream_t stream, int which)
+{
+    if (!g_prof_on) return;
+    if (g_prof_used >= g_prof_events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_prof_events.push_back(e);
+    }
+    (void)which;
+    (void)hipEventRecord(g_prof_events[g_prof_used++], stream);
+}
+
+extern "C" int ngcf_prof_enable(int on)
+{
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return NGCF_OK;
+}
+
+// Waits for the recorded events; returns the number of timed spmm launches and their summed duration.
+extern "C" int ngcf_prof_collect(int64_t *n_launches, double *total_ms)
+{
+    if (!n_launches || !total_ms) return fail(NGCF_ERR_ARG, "prof_collect: null argument");
+    double sum = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(g_prof_events[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
+        sum += ms;
+        ++n;
+    }
+    *n_launches = n;
+    *total_ms = sum;
+    g_prof_used = 0;
+    return NGCF_OK;
+}
+
+namespace {
+struct SpmmArgs {
+    const ngcf_csr *c;
+    const float *E;
+    int64_t ldE;
+    int d;
+    float *out;
+    int64_t ldo;
+    float *partial;
+    int dp;
+    hipStream_t stream;
+};
+
+template <int VEC, int LPR, int CH, int U>
+int launch_spmm(const SpmmArgs &a)
+{
+    const ngcf_csr *c = a.c;
+    const int64_t seg_blocks = (c->n_seg + 3) / 4;
+    const int64_t blocks = seg_blocks + (c->n_rows + 3) / 4;
+    if (blocks == 0) return NGCF_OK;
+    if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+    prof_mark(a.stream, 0);
+    spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
+        c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, a.E,
+        a.ldE, a.d, a.out, a.ldo, a.partial, a.dp);
+    LAUNCH_CHECK();
+    prof_mark(a.stream, 1);
+    if (c->n_heavy > 0) {
+        const int64_t fb = (c->n_heavy + 3) / 4;
+        spmm_fixup_kernel<VEC><<<dim3((unsigned)fb), 256, 0, a.stream>>>(c->heavy_row, c->heavy_seg_ptr, c->n_heavy,
+                                                                          a.partial, a.dp, a.d, a.out, a.ldo);
+        LAUNCH_CHECK();
+    }
+    return NGCF_OK;
+}
+}  // namespace
+
+static int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo,
+                         void *workspace, int64_t workspace_bytes, hipStream_t stream)
+{
+    if (!c || !E || !out) return fail(NGCF_ERR_ARG, "spmm: null argument");
+    if (d <= 0 || d > 512) return fail(NGCF_ERR_ARG, "spmm: width d=%d not in [1, 512]", d);
+    if (ldE < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm: leading dimension smaller than d");
+    const int dp = (int)align_up(d, 4);
+    float *partial = nullptr;
+    if (c->n_seg > 0) {
+        const int64_t need = ngcf_spmm_workspace_bytes(c, d);
+        if (!workspace || workspace_bytes < need)
+            return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+        partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    }
+    SpmmArgs a{c, E, ldE, d, out, ldo, partial, dp, stream};
+    const bool vec = (d % 4 == 0) && (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
+    if (vec) {
+        const int nq = d / 4;
+        if (nq <= 8) return launch_spmm<4, 8, 1, 4>(a);
+        if (nq <= 16) return launch_spmm<4, 16, 1, 8>(a);
+        if (nq <= 32) return launch_spmm<4, 32, 1, 8>(a);
+        if (nq <= 64) return launch_spmm<4, 64, 1, 8>(a);
+        return launch_spmm<4, 64, 2, 4>(a);
+    }
+    if (d <= 64) return launch_spmm<1, 64, 1, 8>(a);
+    if (d <= 128) return launch_spmm<1, 64, 2, 4>(a);
+    if (d <= 256) return launch_spmm<1, 64, 4, 2>(a);
+    return launch_spmm<1, 64, 8, 1>(a);
+}
+
+extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
+                                 void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return spmm_dispatch(c, E, ldE, d, LE, ldLE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense half of a layer (NGCF.py:131-146) on the fp32 matrix cores.
+//
+//   M = [LE+E | LE*E] . [W1^T ; W2^T] + (2*b1 + b2)
+// The K dimension is walked in chunks of DC = 16 input columns: a chunk contributes 16 "sum" values
+// and 16 "product" values per row (KC = 32 k-steps), so LE and E are read exactly once.  Weights are
+// packed per call into that chunk order ([n_chunks*32][DOP], zero padded) by pack_weights_kernel.
+// v_mfma_f32_32x32x2_f32: exact fp32 FMA chain per output element.
+// A workgroup of 4 waves owns BM = 32*RW full rows; waves are arranged RW x CW, each wave NT 32x32 tiles,
+// so a whole output row (<= 32*NT*CW columns) lives in one workgroup and the L2 row-normalisation is
+// done in registers + one LDS exchange.
+// ---------------------------------------------------------------------------------------------
+#define NGCF_KC 32
+#define NGCF_DC 16
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void pack_weights_kernel(const float *__restrict__ W1, const float *__restrict__ b1,
+                                    const float *__restrict__ W2, const float *__restrict__ b2, int d_in, int d_out,
+                                    int n_chunks, int DOP, float *__restrict__ Wt, float *__restrict__ bias2)
+{
+    const int total = n_chunks * NGCF_KC * DOP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i % DOP;
+        const int k = i / DOP;
+        const int chunk = k / NGCF_KC, kl = k % NGCF_KC;
+        const int col = chunk * NGCF_DC + (kl % NGCF_DC);
+        float w = 0.f;
+        if (j < d_out && col < d_in) w = (kl < NGCF_DC ? W1 : W2)[(int64_t)j * d_in + col];
+        Wt[i] = w;
+    }
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < DOP; j += gridDim.x * blockDim.x)
+        bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
+}
+
+// counter-based hash for the message dropout (keep mask is a pure function of seed,row,col)
+__device__ inline uint32_t mix32(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+
+template <int RW, int CW, int NT, bool ALIGNED>
+__global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restrict__ LE, int64_t ldLE,
+                                                          const float *__restrict__ Es, int64_t ldE, int64_t n_rows,
+                                                          int d_in, int d_out, const float *__restrict__ Wt,
+                                                          const float *__restrict__ bias2, int n_chunks,
+                                                          float leaky, float drop_p, uint64_t drop_seed,
+                                                          float *__restrict__ carry, int64_t ldc,
+                                                          float *__restrict__ norm, int64_t ldn)
+{
+    constexpr int BM = 32 * RW;
+    constexpr int WCOLS = 32 * NT * CW;      // == DOP
+    constexpr int XLD = NGCF_KC + 1;         // +1 pad: conflict-free column reads
+    __shared__ float Xs[BM * XLD];
+    __shared__ float Ws[NGCF_KC * WCOLS];
+    __shared__ float ssq[BM * CW];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int rw = wave / CW, cw = wave % CW;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging roles: 4 lanes x 4 columns cover the 16 input columns of a chunk for one row
+    const int sq = tid & 3;
+    const int sr = tid >> 2;   // 0..63
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        // ---- stage X chunk: rows sr, sr+64, ... ; columns chunk*16 + sq*4 .. +4
+        const int c0 = chunk * NGCF_DC + sq * 4;
+#pragma unroll
+        for (int rr = 0; rr < (BM + 63) / 64; ++rr) {
+            const int r = sr + rr * 64;
+            if (r < BM) {
+                float le[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+                const int64_t grow = row0 + r;
+                if (grow < n_rows) {
+                    if (ALIGNED && c0 + 4 <= d_in) {
+                        const float4 a = *reinterpret_cast<const float4 *>(LE + grow * ldLE + c0);
+                        const float4 b = *reinterpret_cast<const float4 *>(Es + grow * ldE + c0);
+                        le[0] = a.x; le[1] = a.y; le[2] = a.z; le[3] = a.w;
+                        e[0] = b.x; e[1] = b.y; e[2] = b.z; e[3] = b.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c0 + q < d_in) {
+                                le[q] = LE[grow * ldLE + c0 + q];
+                                e[q] = Es[grow * ldE + c0 + q];
+                            }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    Xs[r * XLD + sq * 4 + q] = le[q] + e[q];                 // (LE + E)   -> W1
+                    Xs[r * XLD + NGCF_DC + sq * 4 + q] = le[q] * e[q];       // (LE * E)   -> W2
+                }
+            }
+        }
+        // ---- stage W chunk: KC x WCOLS contiguous floats
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
+            float4 *dst = reinterpret_cast<float4 *>(Ws);
+#pragma unroll
+            for (int i = 0; i < (NGCF_KC * WCOLS / 4) / 256; ++i) dst[tid + i * 256] = src[tid + i * 256];
+        }
+        __syncthreads();
+        // ---- MFMA over the 32 k-values of the chunk
+#pragma unroll 4
+        for (int s = 0; s < NGCF_KC / 2; ++s) {
+            const int k = 2 * s + lh;
+            const float a = Xs[(rw * 32 + li) * XLD + k];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = Ws[k * WCOLS + (cw * NT + t) * 32 + li];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, LeakyReLU, dropout, row sum of squares
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    float rowss[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = (cw * NT + t) * 32 + li;
+        const float bz = bias2[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + bz;
+            v = v >= 0.f ? v : leaky * v;
+            if (drop_p > 0.f) {
+                const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                v = h < drop_thr ? 0.f : v * keep_scale;
+            }
+            acc[t][r] = v;
+            rowss[r] = fmaf(v, v, rowss[r]);
+        }
+    }
+    // reduce over the 32 lanes that share a row (lanes li = 0..31 within each half)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = rowss[r];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        rowss[r] = s;
+    }
+    if (CW > 1) {
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ssq[lr * CW + cw] = rowss[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < CW; ++q) s += ssq[lr * CW + q];
+            rowss[r] = s;
+        }
+    }
+    // ---- stores: carry (un-normalised, feeds the next layer) and the normalised all_E block
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= n_rows) continue;
+        const float nrm = fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
+        const float inv = 1.f / nrm;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = (cw * NT + t) * 32 + li;
+            if (col < d_out) {
+                const float v = acc[t][r];
+                if (carry) carry[grow * ldc + col] = v;
+                norm[grow * ldn + col] = v * inv;
+            }
+        }
+    }
+}
+
+static int dense_dop(int d_out)
+{
+    if (d_out <= 32) return 32;
+    if (d_out <= 64) return 64;
+    if (d_out <= 96) return 96;
+    if (d_out <= 128) return 128;
+    if (d_out <= 256) return 256;
+    if (d_out <= 512) return 512;
+    return -1;
+}
+
+extern "C" int64_t ngcf_dense_workspace_bytes(int d_in, int d_out)
+{
+    const int dop = dense_dop(d_out);
+    if (dop < 0 || d_in <= 0) return -1;
+    const int64_t n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
+    return align_up((n_chunks * NGCF_KC * dop + dop) * (int64_t)sizeof(float), 256) + 256;
+}
+
+template <int RW, int CW, int NT>
+static int launch_dense(bool al, int64_t n_rows, const float *LE, int64_t ldLE, const float *Es, int64_t ldE, int d_in,
+                        int d_out, const float *Wt, const float *bias2, int n_chunks, float leaky, float drop_p,
+                        uint64_t seed, float *carry, int64_t ldc, float *norm, int64_t ldn, hipStream_t stream)
+{
+    const int64_t blocks = (n_rows + 32 * RW - 1) / (32 * RW);
+    if (blocks == 0) return NGCF_OK;
+    if (al)
+        layer_dense_kernel<RW, CW, NT, true><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+    else
+        layer_dense_kernel<RW, CW, NT, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *Es, int64_t ldEs, int64_t n_rows,
+                                    int d_in, const float *W1, const float *b1, const float *W2, const float *b2,
+                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, float *carry,
+                                    int64_t ldc, float *norm, int64_t ldn, void *workspace, int64_t workspace_bytes,
+                                    void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!LE || !Es || !W1 || !b1 || !W2 || !b2 || !norm) return fail(NGCF_ERR_ARG, "layer_dense: null argument");
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0) return fail(NGCF_ERR_ARG, "layer_dense: bad sizes");
+    const int dop = dense_dop(d_out);
+    if (dop < 0) return fail(NGCF_ERR_ARG, "layer_dense: d_out=%d > 512 is not supported", d_out);
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "layer_dense: drop_p=%f not in [0,1)", drop_p);
+    if (ldLE < d_in || ldEs < d_in || ldn < d_out || (carry && ldc < d_out))
+        return fail(NGCF_ERR_ARG, "layer_dense: leading dimension too small");
+    const int64_t need = ngcf_dense_workspace_bytes(d_in, d_out);
+    if (!workspace || workspace_bytes < need)
+        return fail(NGCF_ERR_WORKSPACE, "layer_dense: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    const int n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
+    float *Wt = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    float *bias2 = Wt + (int64_t)n_chunks * NGCF_KC * dop;
+    pack_weights_kernel<<<64, 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, Wt, bias2);
+    LAUNCH_CHECK();
+    const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
+#define NGCF_DENSE(RW, CW, NT) \
+    return launch_dense<RW, CW, NT>(al, n_rows, LE, ldLE, Es, ldEs, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, \
+                                    drop_seed, carry, ldc, norm, ldn, stream)
+    switch (dop) {
+    case 32: NGCF_DENSE(4, 1, 1);
+    case 64: NGCF_DENSE(4, 1, 2);
+    case 96: NGCF_DENSE(4, 1, 3);
+    case 128: NGCF_DENSE(4, 1, 4);
+    case 256: NGCF_DENSE(2, 2, 4);
+    default: NGCF_DENSE(1, 4, 4);
+    }
+#undef NGCF_DENSE
+}
+
+extern "C" int64_t ngcf_layer_workspace_bytes(const ngcf_csr_t *c, int d_in, int d_out)
+{
+    if (!c) return -1;
+    const int64_t a = ngcf_spmm_workspace_bytes(c, d_in);
+    const int64_t b = ngcf_dense_workspace_bytes(d_in, d_out);
+    if (a < 0 || b < 0) return -1;
+    const int64_t le = align_up(c->n_rows * align_up(d_in, 4) * (int64_t)sizeof(float), 256);
+    return a + b + le + 256;
+}
+
+extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_t ldEg, const float *Es, int64_t ldEs,
+                                    int d_in, const float *W1, const float *b1, const float *W2, const float *b2,
+                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, float *carry,
+                                    int64_t ldc, float *norm, int64_t ldn, void *workspace, int64_t workspace_bytes,
+                                    void *stream)
+{
+    if (!c) return fail(NGCF_ERR_ARG, "layer_fused: null csr");
+    const int64_t need = ngcf_layer_workspace_bytes(c, d_in, d_out);
+    if (need < 0) return fail(NGCF_ERR_ARG, "layer_fused: unsupported widths d_in=%d d_out=%d", d_in, d_out);
+    if (!workspace || workspace_bytes < need)
+        return fail(NGCF_ERR_WORKSPACE, "layer_fused: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    char *ws = reinterpret_cast<char *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    const int64_t ldLE = align_up(d_in, 4);
+    float *LE = reinterpret_cast<float *>(ws);
+    ws += align_up(c->n_rows * ldLE * (int64_t)sizeof(float), 256);
+    const int64_t spmm_ws = ngcf_spmm_workspace_bytes(c, d_in);
+    void *ws_spmm = ws;
+    ws += spmm_ws;
+    const int64_t dense_ws = ngcf_dense_workspace_bytes(d_in, d_out);
+    void *ws_dense = ws;
+    int rc = ngcf_spmm_csr_f32(c, Eg, ldEg, d_in, LE, ldLE, ws_spmm, spmm_ws, stream);
+    if (rc != NGCF_OK) return rc;
+    return ngcf_layer_dense_f32(LE, ldLE, Es, ldEs, c->n_rows, d_in, W1, b1, W2, b2, d_out, leaky, drop_p, drop_seed,
+                                carry, ldc, norm, ldn, ws_dense, dense_ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided row copy (E0 -> its block of all_E), NGCF.py:120-121,147
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void copy_rows_kernel(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
+                                 int64_t n_rows, int d)
+{
+    using V = typename VecT<VEC>::type;
+    const int per_row = d / VEC;
+    const int64_t total = n_rows * per_row;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t r = i / per_row;
+        const int q = (int)(i % per_row) * VEC;
+        *reinterpret_cast<V *>(dst + r * ldd + q) = *reinterpret_cast<const V *>(src + r * lds + q);
+    }
+}
+
+extern "C" int ngcf_copy_rows_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int d,
+                                  void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst || d <= 0 || n_rows < 0 || lds < d || ldd < d) return fail(NGCF_ERR_ARG, "copy_rows: bad argument");
+    if (n_rows == 0) return NGCF_OK;
+    const bool vec = d % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst);
+    if (vec)
+        copy_rows_kernel<4><<<grid_for(n_rows * (d / 4), 256), 256, 0, stream>>>(src, lds, dst, ldd, n_rows, d);
+    else
+        copy_rows_kernel<1><<<grid_for(n_rows * d, 256), 256, 0, stream>>>(src, lds, dst, ldd, n_rows, d);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// feature injection, NGCF.py:103-115
+// ---------------------------------------------------------------------------------------------
+struct InjectTables {
+    const float *table[5];
+    const int64_t *idx[5];
+    int64_t card[5];
+};
+
+// pass 1: winner[u] = max batch position that names user u (last occurrence wins)
+__global__ void inject_claim_kernel(const int64_t *__restrict__ u_id, int64_t B, int64_t n_user, int32_t *winner,
+                                    int32_t *status)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t u = u_id[b];
+    if (u < 0 || u >= n_user) {
+        atomicOr(status, 1);
+        return;
+    }
+    atomicMax(&winner[u], (int32_t)b);
+}
+
+// pass 2: the winning occurrence writes row u; one wave per batch position
+__global__ __launch_bounds__(256) void inject_write_kernel(float *__restrict__ user_w, int64_t ldu, int64_t n_user,
+                                                           int d0, InjectTables t, int fw,
+                                                           const int64_t *__restrict__ u_id, int64_t B, float ratio,
+                                                           float one_minus_ratio,
+                                                           const int32_t *__restrict__ winner, int32_t *status)
+{
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t u = u_id[b];
+    if (u < 0 || u >= n_user) return;
+    if (winner[u] != (int32_t)b) return;
+    bool bad = false;
+    int64_t fi[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        fi[f] = t.idx[f][b];
+        bad |= fi[f] < 0 || fi[f] >= t.card[f];
+    }
+    if (bad) {
+        if (lane == 0) atomicOr(status, 1);
+        return;
+    }
+    float *row = user_w + u * ldu;
+    for (int j = lane; j < d0; j += 64) {
+        const int f = j / fw, k = j % fw;
+        const float feat = t.table[f][fi[f] * fw + k];
+        // two rounded products and one rounded add, as torch evaluates NGCF.py:114-115 (no FMA contraction)
+        row[j] = __fadd_rn(__fmul_rn(row[j], one_minus_ratio), __fmul_rn(feat, ratio));
+    }
+}
+
+// pass 3: restore scratch to -1
+__global__ void inject_reset_kernel(const int64_t *__restrict__ u_id, int64_t B, int64_t n_user, int32_t *winner)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t u = u_id[b];
+    if (u >= 0 && u < n_user) winner[u] = -1;
+}
+
+extern "C" int ngcf_feature_inject_f32(float *user_w, int64_t ldu, int64_t n_user, int d0, const float *const *tables,
+                                       const int64_t *const *idx, const int64_t *cards, int fw, const int64_t *u_id,
+                                       int64_t B, double emb_ratio, int32_t *scratch, int32_t *status, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!user_w || !tables || !idx || !cards || !scratch || !status) return fail(NGCF_ERR_ARG, "feature_inject: null argument");
+    if (B < 0 || B >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "feature_inject: bad batch size");
+    if (5 * fw != d0)
+        return fail(NGCF_ERR_ARG,
+                    "feature_inject: shape mismatch: 5 feature tables of width %d give %d columns, user rows have %d "
+                    "(embed_size must be a multiple of 5, NGCF.py:39-43,114)", fw, 5 * fw, d0);
+    if (B == 0) return NGCF_OK;
+    if (!u_id) return fail(NGCF_ERR_ARG, "feature_inject: null u_id");
+    InjectTables t;
+    for (int f = 0; f < 5; ++f) {
+        if (!tables[f] || !idx[f]) return fail(NGCF_ERR_ARG, "feature_inject: null table/index %d", f);
+        t.table[f] = tables[f];
+        t.idx[f] = idx[f];
+        t.card[f] = cards[f];
+    }
+    const int tb = (int)((B + 255) / 256);
+    inject_claim_kernel<<<tb, 256, 0, stream>>>(u_id, B, n_user, scratch, status);
+    LAUNCH_CHECK();
+    // `1 - emb_ratio` is a Python double in the reference and reaches the fp32 multiply rounded once
+    inject_write_kernel<<<(int)((B + 3) / 4), 256, 0, stream>>>(user_w, ldu, n_user, d0, t, fw, u_id, B, (float)emb_ratio,
+                                                                 (float)(1.0 - emb_ratio), scratch, status);
+    LAUNCH_CHECK();
+    inject_reset_kernel<<<tb, 256, 0, stream>>>(u_id, B, n_user, scratch);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row gather, NGCF.py:151-155 (bit-exact copies)
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ table, int64_t ld, int d,
+                                                          const int64_t *__restrict__ idx, int64_t B, int64_t row_off,
+                                                          int64_t n_idx_rows, float *__restrict__ out, int64_t ldo,
+                                                          int32_t *status)
+{
+    using V = typename VecT<VEC>::type;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = idx[b];
+    if (i < 0 || i >= n_idx_rows) {
+        if (lane == 0) atomicOr(status, 1);
+        return;
+    }
+    const float *src = table + (row_off + i) * ld;
+    float *dst = out + b * ldo;
+    for (int o = lane * VEC; o < d; o += 64 * VEC) *reinterpret_cast<V *>(dst + o) = *reinterpret_cast<const V *>(src + o);
+}
+
+extern "C" int ngcf_gather_rows_f32(const float *table, int64_t ld, int d, const int64_t *idx, int64_t B,
+                                    int64_t row_off, int64_t n_idx_rows, float *out, int64_t ldo, int32_t *status,
+                                    void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!table || !out || !status || d <= 0 || B < 0 || ld < d || ldo < d) return fail(NGCF_ERR_ARG, "gather_rows: bad argument");
+    if (B == 0) return NGCF_OK;
+    if (!idx) return fail(NGCF_ERR_ARG, "gather_rows: null idx");
+    const bool vec = d % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && aligned16(table) && aligned16(out);
+    const int blocks = (int)((B + 3) / 4);
+    if (vec)
+        gather_rows_kernel<4><<<blocks, 256, 0, stream>>>(table, ld, d, idx, B, row_off, n_idx_rows, out, ldo, status);
+    else
+        gather_rows_kernel<1><<<blocks, 256, 0, stream>>>(table, ld, d, idx, B, row_off, n_idx_rows, out, ldo, status);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BPR, bprloss.py:15-22
+// ---------------------------------------------------------------------------------------------
+__device__ inline float wave_sum(float x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+    return x;
+}
+
+__device__ inline float log_sigmoid(float x)
+{
+    return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+
+// one wave per row r < R; block partials: part[2*block + 0] = -sum logsigmoid, part[2*block + 1] = sum of squares
+__global__ __launch_bounds__(256) void bpr_rows_kernel(const float *__restrict__ u, int64_t Bu, const float *__restrict__ p,
+                                                       int64_t Bp, const float *__restrict__ n, int64_t Bn, int64_t R,
+                                                       int D, float *__restrict__ part)
+{
+    __shared__ float sh[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    float nl = 0.f, sq = 0.f;
+    if (r < R) {
+        const float *ur = u + (Bu == 1 ? 0 : r) * (int64_t)D;
+        const float *pr = p + (Bp == 1 ? 0 : r) * (int64_t)D;
+        const float *nr = n + (Bn == 1 ? 0 : r) * (int64_t)D;
+        float up = 0.f, un = 0.f, uu = 0.f, pp = 0.f, nn = 0.f;
+        for (int j = lane; j < D; j += 64) {
+            const float a = ur[j], b = pr[j], c = nr[j];
+            up = fmaf(a, b, up);
+            un = fmaf(a, c, un);
+            uu = fmaf(a, a, uu);
+            pp = fmaf(b, b, pp);
+            nn = fmaf(c, c, nn);
+        }
+        up = wave_sum(up);
+        un = wave_sum(un);
+        uu = wave_sum(uu);
+        pp = wave_sum(pp);
+        nn = wave_sum(nn);
+        nl = -log_sigmoid(fabsf(up) - fabsf(un));                  // bprloss.py:16-19
+        // each tensor's own rows are counted once (a broadcast row only at r == 0)
+        sq = (r < Bu ? uu : 0.f) + (r < Bp ? pp : 0.f) + (r < Bn ? nn : 0.f);
+    }
+    if (lane == 0) {
+        sh[wave * 2] = nl;
+        sh[wave * 2 + 1] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * (int64_t)blockIdx.x] = (sh[0] + sh[2]) + (sh[4] + sh[6]);
+        part[2 * (int64_t)blockIdx.x + 1] = (sh[1] + sh[3]) + (sh[5] + sh[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_finish_kernel(const float *__restrict__ part, int64_t n_blocks, float wd,
+                                                         float batch_size, float *__restrict__ loss)
+{
+    __shared__ float sh[8];
+    float nl = 0.f, sq = 0.f;
+    for (int64_t i = threadIdx.x; i < n_blocks; i += 256) {
+        nl += part[2 * i];
+        sq += part[2 * i + 1];
+    }
+    nl = wave_sum(nl);
+    sq = wave_sum(sq);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sh[wave * 2] = nl;
+        sh[wave * 2 + 1] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = (sh[0] + sh[2]) + (sh[4] + sh[6]);
+        const float b = (sh[1] + sh[3]) + (sh[5] + sh[7]);
+        *loss = (a + wd * b) / batch_size;                          // bprloss.py:20-22
+    }
+}
+
+extern "C" int64_t ngcf_bpr_workspace_bytes(int64_t R)
+{
+    if (R < 0) return -1;
+    return align_up(((R + 3) / 4) * 2 * (int64_t)sizeof(float), 256) + 256;
+}
+
+extern "C" int ngcf_bpr_fused_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, const float *n, int64_t Bn,
+                                  int D, float wd, float batch_size, float *loss, void *workspace,
+                                  int64_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!u || !p || !n || !loss || D <= 0) return fail(NGCF_ERR_ARG, "bpr: null argument");
+    const int64_t R = std::max(Bu, std::max(Bp, Bn));
+    if (R < 1) return fail(NGCF_ERR_ARG, "bpr: empty operand (rows %lld/%lld/%lld)", (long long)Bu, (long long)Bp, (long long)Bn);
+    if ((Bu != 1 && Bu != R) || (Bp != 1 && Bp != R) || (Bn != 1 && Bn != R))
+        return fail(NGCF_ERR_ARG, "bpr: row counts %lld/%lld/%lld do not broadcast", (long long)Bu, (long long)Bp, (long long)Bn);
+    const int64_t need = ngcf_bpr_workspace_bytes(R);
+    if (!workspace || workspace_bytes < need)
+        return fail(NGCF_ERR_WORKSPACE, "bpr: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    float *part = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    const int64_t blocks = (R + 3) / 4;
+    bpr_rows_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(u, Bu, p, Bp, n, Bn, R, D, part);
+    LAUNCH_CHECK();
+    bpr_finish_kernel<<<1, 256, 0, stream>>>(part, blocks, wd, batch_size, loss);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row partition helper (host only)
+// ---------------------------------------------------------------------------------------------
+extern "C" int ngcf_shard_plan(const int64_t *rowptr, int64_t row_begin, int64_t row_end, int world, int64_t *bounds)
+{
+    if (!rowptr || !bounds || world < 1 || row_begin < 0 || row_end < row_begin)
+        return fail(NGCF_ERR_ARG, "shard_plan: bad argument");
+    const int64_t total = rowptr[row_end] - rowptr[row_begin];
+    bounds[0] = row_begin;
+    int64_t r = row_begin;
+    for (int w = 1; w < world; ++w) {
+        // first row whose prefix reaches w/world of the entries
+        const int64_t target = rowptr[row_begin] + (total * w) / world;
+        const int64_t *it = std::lower_bound(rowptr + r, rowptr + row_end + 1, target);
+        int64_t cut = it - rowptr;
+        // of the two row boundaries around the target take the nearer one
+        if (cut > r && cut <= row_end && target - rowptr[cut - 1] < rowptr[cut] - target) --cut;
+        if (cut < r) cut = r;
+        if (cut > row_end) cut = row_end;
+        if (total == 0) cut = row_begin + ((row_end - row_begin) * w) / world;
+        bounds[w] = cut;
+        r = cut;
+    }
+    bounds[world] = row_end;
+    return NGCF_OK;
+}
