@@ -1089,9 +1089,9 @@ extern "C" int ngcf_gather_rows_f32(const float *table, int64_t ld, int d, const
                                     void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!table || !out || !status || d <= 0 || B < 0 || ld < d || ldo < d) return fail(NGCF_ERR_ARG, "gather_rows: bad argument");
     if (B == 0) return NGCF_OK;
-    if (!idx) return fail(NGCF_ERR_ARG, "gather_rows: null idx");
+    if (!table || !out || !status || !idx || d <= 0 || B < 0 || ld < d || ldo < d)
+        return fail(NGCF_ERR_ARG, "gather_rows: bad argument");
     const bool vec = d % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && aligned16(table) && aligned16(out);
     const int blocks = (int)((B + 3) / 4);
     if (vec)
