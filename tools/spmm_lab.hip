@@ -1,0 +1,44 @@
+// Experimental SpMM variants (NOT product code): d-slicing and unroll depth on top of the product's
+// spmm_accumulate.  One wave per work unit (row or row segment); units come from tools/spmm_lab.py.
+#include "../seoul_tourism_recommendation_ngcf_amd/csrc/ngcf_hip.hip"
+
+// LPR lanes cover one slice of S = 4*LPR floats of a gathered row; G = 64/LPR rows per wave-instruction.
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void lab_spmm(const int64_t *__restrict__ ubeg, const int64_t *__restrict__ uend,
+                                                const int64_t *__restrict__ udst, int64_t n_units, int64_t unit_blocks,
+                                                const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                                const float *__restrict__ E, int64_t ldE, float *__restrict__ out,
+                                                int64_t ldo)
+{
+    const int64_t slice = blockIdx.x / unit_blocks;
+    const int64_t ub = blockIdx.x % unit_blocks;
+    const int64_t unit = ub * 4 + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    constexpr int S = LPR * 4;
+    float4 acc[1];
+    acc[0] = vzero4();
+    spmm_accumulate<4, LPR, 1, U>(colidx, vals, ubeg[unit], uend[unit], E + slice * S, ldE, S, acc);
+    spmm_store<4, LPR, 1>(acc, out + udst[unit] * ldo + slice * S, S);
+}
+
+extern "C" int lab_launch(int variant, const int64_t *ubeg, const int64_t *uend, const int64_t *udst, int64_t n_units,
+                          const int32_t *colidx, const float *vals, const float *E, int64_t ldE, int d, float *out,
+                          int64_t ldo, void *stream_)
+{
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t ubk = (n_units + 3) / 4;
+#define GO(LPR, U) \
+    lab_spmm<LPR, U><<<dim3((unsigned)(ubk * (d / (4 * LPR)))), 256, 0, s>>>(ubeg, uend, udst, n_units, ubk, colidx, vals, E, ldE, out, ldo)
+    switch (variant) {
+    case 0: GO(32, 8); break;      // full width (d=128), the product kernel's shape
+    case 1: GO(32, 4); break;
+    case 2: GO(32, 16); break;
+    case 3: GO(16, 8); break;      // 2 slices of 64 floats
+    case 4: GO(16, 16); break;
+    case 5: GO(8, 8); break;       // 4 slices of 32 floats (one 128-B line per gathered row)
+    case 6: GO(8, 16); break;
+    case 7: GO(8, 4); break;
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
