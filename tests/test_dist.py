@@ -1,0 +1,215 @@
+"""Multi-rank tests, world_size 2 over `gloo`.
+
+CPU (not gpu): the partition/layout/exchange plumbing of seoul_tourism_recommendation_ngcf_amd/dist.py
+(ShardLayout, slab_coo, allgather_rows, owner_rows_sum) drives a two-rank propagation whose per-slab
+arithmetic is done by the ORACLE inside the test; the result must equal the unsharded oracle.  This checks
+that the exchange is correct by construction without any CPU compute path in the product.
+
+GPU (-m gpu): two ranks share cuda:0 (RCCL refuses two ranks on one device, so the process group is gloo
+on device tensors); `ShardedPropagation` runs the real HIP kernels in both exchange schemes and must match
+the single-GPU engine.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ngcf_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy_graph(n_user, n_item, n_inter, seed):
+    """Same generator as graphs.synthetic_bipartite, on the CPU generator."""
+    from seoul_tourism_recommendation_ngcf_amd import graphs
+    return graphs.synthetic_bipartite(n_user, n_item, n_inter, seed=seed, device="cpu")
+
+
+def _params(d0, layers, seed):
+    g = torch.Generator().manual_seed(seed)
+    dims = [d0] + list(layers)
+    w1 = [(torch.rand((dims[k + 1], dims[k]), generator=g) - 0.5) * 0.3 for k in range(len(layers))]
+    w2 = [(torch.rand((dims[k + 1], dims[k]), generator=g) - 0.5) * 0.3 for k in range(len(layers))]
+    b1 = [(torch.rand((dims[k + 1],), generator=g) - 0.5) * 0.1 for k in range(len(layers))]
+    b2 = [(torch.rand((dims[k + 1],), generator=g) - 0.5) * 0.1 for k in range(len(layers))]
+    return w1, b1, w2, b2
+
+
+def _dense_oracle(LE, E, W1, b1, W2, b2):
+    M = torch.nn.functional.linear(LE, W1, b1) + torch.nn.functional.linear(E, W1, b1) \
+        + torch.nn.functional.linear(LE * E, W2, b2)
+    c = torch.nn.functional.leaky_relu(M, 0.2)
+    return c, torch.nn.functional.normalize(c, p=2, dim=1)
+
+
+def _cpu_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seoul_tourism_recommendation_ngcf_amd import dist as nd
+        U, I, d0, layers = 300, 40, 16, (16, 12)
+        coo = _toy_graph(U, I, 3000, seed=5)
+        rows, cols, vals = coo["rows"], coo["cols"], coo["vals"]
+        N = U + I
+        g = torch.Generator().manual_seed(1)
+        E0 = torch.randn((N, d0), generator=g)
+        w1, b1, w2, b2 = _params(d0, layers, 2)
+        L = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (N, N))
+        want = orc.propagate_torch(L, E0[:U], E0[U:], w1, b1, w2, b2)
+
+        # ---- all-gather scheme: padded rank-major layout, one collective per node group and layer
+        cnt = nd.row_counts(rows, N)
+        ub = nd.balanced_bounds(cnt, 0, U, world)
+        ib = nd.balanced_bounds(cnt, U, N, world)
+        lay = nd.ShardLayout(U, I, ub, ib)
+        pc = lay.to_padded(cols)
+        assert torch.equal(torch.sort(lay.to_padded(torch.arange(N))).values.unique(), torch.sort(lay.to_padded(torch.arange(N))).values)
+        full = torch.full((lay.P, d0), float("nan"))
+        for q in range(world):
+            full[lay.user_pos(q):lay.user_pos(q) + lay.n_users_of(q)] = E0[ub[q]:ub[q + 1]]
+            full[lay.item_pos(q):lay.item_pos(q) + lay.n_items_of(q)] = E0[ib[q]:ib[q + 1]]
+        nu, ni = lay.n_users_of(rank), lay.n_items_of(rank)
+        blocks_u, blocks_i = [E0[ub[rank]:ub[rank + 1]]], [E0[ib[rank]:ib[rank + 1]]]
+        for k in range(len(layers)):
+            outs = []
+            for (lo, hi, pos, n_own, m) in ((ub[rank], ub[rank + 1], lay.user_pos(rank), nu, lay.mu),
+                                            (ib[rank], ib[rank + 1], lay.item_pos(rank), ni, lay.mi)):
+                r_, c_, v_ = nd.slab_coo(rows, pc, vals, lo, hi)
+                Ls = torch.sparse_coo_tensor(torch.stack([r_, c_]), v_, (n_own, lay.P))
+                table = torch.nan_to_num(full, nan=0.0)           # padding rows are never referenced
+                LE = torch.mm(Ls, table)
+                carry, nrm = _dense_oracle(LE, full[pos:pos + n_own], w1[k], b1[k], w2[k], b2[k])
+                send = torch.full((m, carry.shape[1]), float("nan"))
+                send[:n_own] = carry
+                outs.append((send, nrm))
+            nxt = torch.empty((lay.P, outs[0][0].shape[1]))
+            nd.allgather_rows(nxt[:world * lay.mu], outs[0][0])
+            nd.allgather_rows(nxt[world * lay.mu:], outs[1][0])
+            blocks_u.append(outs[0][1])
+            blocks_i.append(outs[1][1])
+            full = nxt
+        got_u, got_i = torch.cat(blocks_u, 1), torch.cat(blocks_i, 1)
+        assert torch.allclose(got_u, want[ub[rank]:ub[rank + 1]], atol=1e-6)
+        assert torch.allclose(got_i, want[ib[rank]:ib[rank + 1]], atol=1e-6)
+        # owner-served row gathers: every rank ends with all rows
+        u_id = torch.tensor([0, U - 1, 17, ub[1], ub[1] - 1, 5])
+        ow, loc = lay.owner_of_user(u_id)
+        mine = ow == rank
+        local = got_u[torch.where(mine, loc, torch.zeros_like(loc))]
+        assert torch.allclose(nd.owner_rows_sum(local, mine), want[:U][u_id], atol=1e-6)
+        it = torch.tensor([0, I - 1, 3, ib[1] - U])
+        ow, loc = lay.owner_of_item(it)
+        mine = ow == rank
+        local = got_i[torch.where(mine, loc, torch.zeros_like(loc))]
+        assert torch.allclose(nd.owner_rows_sum(local, mine), want[U:][it], atol=1e-6)
+
+        # ---- bipartite scheme: users partitioned, items replicated, one all-reduce per layer
+        eb = nd.even_bounds(0, U, world)
+        lo, hi = eb[rank], eb[rank + 1]
+        n_ue = int(torch.searchsorted(rows, torch.tensor([U])))
+        ur, uc, uv = nd.slab_coo(rows, cols, vals, lo, hi)
+        Lu = torch.sparse_coo_tensor(torch.stack([ur, uc - U]), uv, (hi - lo, I))
+        ir, ic, iv = rows[n_ue:] - U, cols[n_ue:], vals[n_ue:]
+        sel = (ic >= lo) & (ic < hi)
+        Lit = torch.sparse_coo_tensor(torch.stack([ir[sel], ic[sel] - lo]), iv[sel], (I, hi - lo))
+        eu, ei = E0[lo:hi], E0[U:]
+        bu, bi = [eu], [ei]
+        for k in range(len(layers)):
+            part = torch.mm(Lit, eu)
+            work = dist.all_reduce(part, async_op=True)
+            cu, nu_ = _dense_oracle(torch.mm(Lu, ei), eu, w1[k], b1[k], w2[k], b2[k])
+            work.wait()
+            ci, ni_ = _dense_oracle(part, ei, w1[k], b1[k], w2[k], b2[k])
+            bu.append(nu_)
+            bi.append(ni_)
+            eu, ei = cu, ci
+        assert torch.allclose(torch.cat(bu, 1), want[lo:hi], atol=1e-6)
+        assert torch.allclose(torch.cat(bi, 1), want[U:], atol=1e-6)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_plumbing_on_gloo_cpu():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_cpu_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_layout_and_bounds_single_process():
+    from seoul_tourism_recommendation_ngcf_amd import dist as nd
+    cnt = torch.tensor([1, 1, 1, 1, 50, 2, 2, 2, 2, 40])          # 5 users, 5 items
+    ub = nd.balanced_bounds(cnt, 0, 5, 2)
+    ib = nd.balanced_bounds(cnt, 5, 10, 2)
+    assert ub[0] == 0 and ub[-1] == 5 and ib[0] == 5 and ib[-1] == 10
+    lay = nd.ShardLayout(5, 5, ub, ib)
+    pos = lay.to_padded(torch.arange(10))
+    assert len(set(pos.tolist())) == 10 and int(pos.max()) < lay.P
+    for q in range(2):                                            # chunks are contiguous and rank-major
+        assert pos[ub[q]:ub[q + 1]].tolist() == list(range(lay.user_pos(q), lay.user_pos(q) + lay.n_users_of(q)))
+        assert pos[ib[q]:ib[q + 1]].tolist() == list(range(lay.item_pos(q), lay.item_pos(q) + lay.n_items_of(q)))
+    assert nd.even_bounds(0, 10, 4) == [0, 2, 5, 7, 10]
+    r, c, v = nd.slab_coo(torch.tensor([0, 0, 2, 3, 3]), torch.arange(5), torch.ones(5), 2, 4)
+    assert r.tolist() == [0, 1, 1] and c.tolist() == [2, 3, 4]
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the real sharded HIP path, two ranks on one device
+# ------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, mode, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import seoul_tourism_recommendation_ngcf_amd as pkg
+        from seoul_tourism_recommendation_ngcf_amd import dist as nd
+        dev = torch.device("cuda:0")
+        U, I = 6000, 500
+        coo = pkg.graphs.synthetic_bipartite(U, I, 90000, seed=3, device=dev)
+        num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+        torch.manual_seed(7)
+        model = pkg.NGCF(128, [128, 64], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 64, dev).to(dev).eval()
+        want = model.propagate(0).clone()
+        sh = nd.ShardedPropagation(model, coo["rows"], coo["cols"], coo["vals"], mode=mode)
+        au, ai = sh.propagate()
+        if mode == "bipartite":
+            lo, hi = sh.ub[rank], sh.ub[rank + 1]
+            ok = torch.allclose(au, want[lo:hi], atol=2e-5, rtol=2e-3) and torch.allclose(ai, want[U:], atol=2e-5, rtol=2e-3)
+        else:
+            lay = sh.layout
+            ok = torch.allclose(au, want[lay.ub[rank]:lay.ub[rank + 1]], atol=2e-5, rtol=2e-3) and \
+                torch.allclose(ai, want[lay.ib[rank]:lay.ib[rank + 1]], atol=2e-5, rtol=2e-3)
+        g = torch.Generator().manual_seed(11)
+        u_id = torch.randint(0, U, (64,), generator=g).to(dev)
+        pos = torch.randint(0, I, (64,), generator=g).to(dev)
+        neg = torch.randint(0, I, (64,), generator=g).to(dev)
+        u, p, n = sh.gather(u_id, pos, neg)
+        ok = ok and torch.allclose(u, want[:U][u_id], atol=2e-5, rtol=2e-3) and torch.allclose(p, want[U:][pos], atol=2e-5, rtol=2e-3) \
+            and torch.allclose(n, want[U:][neg], atol=2e-5, rtol=2e-3)
+        loss = pkg.BPR(0.025, 64)(u, p, n)
+        ref = orc.bpr_torch(want[:U][u_id].cpu(), want[U:][pos].cpu(), want[U:][neg].cpu(), 0.025, 64)
+        ok = ok and abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bipartite", "allgather"])
+def test_sharded_propagation_two_ranks_one_gpu(mode):
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gpu_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
