@@ -70,6 +70,10 @@ int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx, const flo
 /* Re-plan the row segmentation: rows with more than `seg_len` stored entries are cut into
  * segments of `seg_len` entries whose partial sums are combined in a fixed order (no atomics). */
 int ngcf_csr_plan(ngcf_csr_t *csr, int32_t seg_len, void *stream);
+/* SpMM kernel choice: 0 = automatic (the L2-swept kernel for matrices with >= 2^22 stored entries and widths
+ * that are multiples of 64, the row-wise gather kernel otherwise), 1 = row-wise kernel only, 2 = swept kernel
+ * whenever the width allows (builds its plan on the host if missing; used by tests on small matrices). */
+int ngcf_csr_set_mode(ngcf_csr_t *csr, int mode, void *stream);
 void ngcf_csr_free(ngcf_csr_t *csr);
 int64_t ngcf_csr_nnz(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_rows(const ngcf_csr_t *csr);

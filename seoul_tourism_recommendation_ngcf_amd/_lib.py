@@ -27,6 +27,7 @@ PROTOTYPES = {
     "ngcf_csr_from_coo": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(_vp), _vp]),
     "ngcf_csr_from_arrays": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(_vp), _vp]),
     "ngcf_csr_plan": (C.c_int, [_vp, _i32, _vp]),
+    "ngcf_csr_set_mode": (C.c_int, [_vp, C.c_int, _vp]),
     "ngcf_csr_free": (None, [_vp]),
     "ngcf_csr_nnz": (_i64, [_vp]),
     "ngcf_csr_n_rows": (_i64, [_vp]),

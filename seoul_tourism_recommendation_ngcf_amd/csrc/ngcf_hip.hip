@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "../../include/ngcf_hip.h"
@@ -75,9 +76,38 @@ struct ngcf_csr {
     int64_t *seg_begin = nullptr;      // device [n_seg]   first entry of each segment
     int32_t *heavy_row = nullptr;      // device [n_heavy] rows that were cut
     int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1] their segment ranges
+    // row groups: maximal runs of rows whose gathered column range is small enough that d-slicing pays
+    struct RowGroup { int64_t begin, end; bool sliceable; };
+    std::vector<RowGroup> groups;
+    // L2-swept plan (see "swept SpMM" below); experimental, only on request
+    int mode = 0;                      // 0/1 row-wise kernels, 2 swept kernel whenever the width allows
+    struct Swept {
+        int64_t n_owners = 0, n_entries = 0, n_partial = 0, n_heavy = 0;
+        int32_t block_cols = 0, n_blocks = 0, n_rounds = 0;
+        int64_t *own_ptr = nullptr;        // device [n_owners+1]   entry range of each owner
+        int32_t *e_col = nullptr;          // device [n_entries]    column, sorted by (column block, row) per owner
+        float *e_val = nullptr;            // device [n_entries]
+        uint8_t *e_row = nullptr;          // device [n_entries]    owner-local row id (0..15)
+        int64_t *own_dst = nullptr;        // device [n_owners*16]  >=0 output row, <0 partial -1-p, INT64_MIN unused
+        int32_t *heavy_row = nullptr;      // device [n_heavy]
+        int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1]
+    } swept;
 };
 
 static const int32_t kDefaultSegLen = 512;
+
+static void free_swept(ngcf_csr *c)
+{
+    ngcf_csr::Swept &w = c->swept;
+    if (w.own_ptr) (void)hipFree(w.own_ptr);
+    if (w.e_col) (void)hipFree(w.e_col);
+    if (w.e_val) (void)hipFree(w.e_val);
+    if (w.e_row) (void)hipFree(w.e_row);
+    if (w.own_dst) (void)hipFree(w.own_dst);
+    if (w.heavy_row) (void)hipFree(w.heavy_row);
+    if (w.heavy_seg_ptr) (void)hipFree(w.heavy_seg_ptr);
+    w = ngcf_csr::Swept();
+}
 
 static void free_plan(ngcf_csr *c)
 {
@@ -96,6 +126,7 @@ extern "C" void ngcf_csr_free(ngcf_csr_t *c)
 {
     if (!c) return;
     free_plan(c);
+    free_swept(c);
     if (c->owns) {
         if (c->rowptr) (void)hipFree(c->rowptr);
         if (c->colidx) (void)hipFree(c->colidx);
@@ -164,6 +195,79 @@ static int grid_for(int64_t n, int block)
     return (int)g;
 }
 
+
+// per 1024-row block: smallest and largest column any of its rows gathers (one-time, plan only)
+#define NGCF_GROUP_ROWS 1024
+__global__ void row_colrange_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                    int64_t n_rows, int32_t *__restrict__ blk_min, int32_t *__restrict__ blk_max)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    int32_t lo = INT32_MAX, hi = -1;
+    for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+        const int32_t c = colidx[e];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+    if (hi >= 0) {
+        atomicMin(&blk_min[row / NGCF_GROUP_ROWS], lo);
+        atomicMax(&blk_max[row / NGCF_GROUP_ROWS], hi);
+    }
+}
+
+// A row block is "sliceable" when one 32-float slice (128 B) of every row it gathers is at most 48 MiB: then the
+// hot part of the table slice lives in the XCD L2s while a slice-major launch walks it (measured on the user half
+// of C3: 2.33 ms sliced vs 2.98 ms unsliced; the 1 M-row user table gets slower sliced: 3.8 vs 3.46 ms).
+static const int64_t kSliceFootprintRows = (48ll << 20) / 128;
+
+static int build_row_groups(ngcf_csr *c, hipStream_t stream)
+{
+    c->groups.clear();
+    if (c->n_rows == 0) return NGCF_OK;
+    const int64_t nb = (c->n_rows + NGCF_GROUP_ROWS - 1) / NGCF_GROUP_ROWS;
+    int32_t *d_min = nullptr, *d_max = nullptr;
+    std::vector<int32_t> h_min((size_t)nb), h_max((size_t)nb);
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&d_min, sizeof(int32_t) * (size_t)nb));
+        HIP_TRY(hipMalloc(&d_max, sizeof(int32_t) * (size_t)nb));
+        HIP_TRY(hipMemsetAsync(d_min, 0x7f, sizeof(int32_t) * (size_t)nb, stream));   // 0x7f7f7f7f: large
+        HIP_TRY(hipMemsetAsync(d_max, 0xff, sizeof(int32_t) * (size_t)nb, stream));   // -1
+        row_colrange_kernel<<<(int)((c->n_rows + 255) / 256), 256, 0, stream>>>(c->rowptr, c->colidx, c->n_rows, d_min, d_max);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(h_min.data(), d_min, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_max.data(), d_max, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return NGCF_OK;
+    };
+    const int rc = body();
+    if (d_min) (void)hipFree(d_min);
+    if (d_max) (void)hipFree(d_max);
+    if (rc != NGCF_OK) return rc;
+    for (int64_t b = 0; b < nb; ++b) {
+        const bool s = h_max[(size_t)b] < 0 || (int64_t)h_max[(size_t)b] - h_min[(size_t)b] + 1 <= kSliceFootprintRows;
+        const int64_t lo = b * NGCF_GROUP_ROWS, hi = std::min<int64_t>(c->n_rows, lo + NGCF_GROUP_ROWS);
+        if (!c->groups.empty() && c->groups.back().sliceable == s)
+            c->groups.back().end = hi;
+        else
+            c->groups.push_back({lo, hi, s});
+    }
+    // a group of a few blocks is not worth its own launch: give it its neighbour's class, then fuse equal neighbours
+    for (size_t i = 0; i < c->groups.size(); ++i)
+        if (c->groups.size() > 1 && c->groups[i].end - c->groups[i].begin < 16 * NGCF_GROUP_ROWS)
+            c->groups[i].sliceable = c->groups[i > 0 ? i - 1 : i + 1].sliceable;
+    for (size_t k = 1; k < c->groups.size();) {
+        if (c->groups[k].sliceable == c->groups[k - 1].sliceable) {
+            c->groups[k - 1].end = c->groups[k].end;
+            c->groups.erase(c->groups.begin() + (long)k);
+        } else {
+            ++k;
+        }
+    }
+    return NGCF_OK;
+}
+
+static int build_swept_plan(ngcf_csr *c, hipStream_t stream);
+
 extern "C" int ngcf_csr_plan(ngcf_csr_t *c, int32_t seg_len, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -201,6 +305,23 @@ extern "C" int ngcf_csr_plan(ngcf_csr_t *c, int32_t seg_len, void *stream_)
         HIP_TRY(hipMemcpyAsync(c->heavy_seg_ptr, heavy_ptr.data(), sizeof(int64_t) * heavy_ptr.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    {
+        const int rc = build_row_groups(c, stream);
+        if (rc != NGCF_OK) return rc;
+    }
+    if (c->swept.n_owners == 0 && c->mode == 2) return build_swept_plan(c, stream);
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_csr_set_mode(ngcf_csr_t *c, int mode, void *stream)
+{
+    if (!c || mode < 0 || mode > 2) return fail(NGCF_ERR_ARG, "ngcf_csr_set_mode: bad argument");
+    c->mode = mode;
+    if (mode != 2) {
+        free_swept(c);
+        return NGCF_OK;
+    }
+    if (c->swept.n_owners == 0) return build_swept_plan(c, (hipStream_t)stream);
     return NGCF_OK;
 }
 
@@ -440,8 +561,8 @@ __device__ inline void spmm_store(typename VecT<VEC>::type (&acc)[CH], float *__
 template <int VEC, int LPR, int CH, int U>
 __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ colidx,
-                                                   const float *__restrict__ vals, int64_t n_rows,
-                                                   const int32_t *__restrict__ seg_row,
+                                                   const float *__restrict__ vals, int64_t row_begin,
+                                                   int64_t n_rows, const int32_t *__restrict__ seg_row,
                                                    const int64_t *__restrict__ seg_begin, int64_t n_seg,
                                                    int64_t seg_blocks, int seg_len,
                                                    const float *__restrict__ E, int64_t ldE, int d,
@@ -460,7 +581,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
         end = begin + seg_len < row_end ? begin + seg_len : row_end;
         dst = partial + s * (int64_t)dp;
     } else {
-        const int64_t row = ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
+        const int64_t row = row_begin + ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
         if (row >= n_rows) return;
         begin = rowptr[row];
         end = rowptr[row + 1];
@@ -472,6 +593,27 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
     for (int ch = 0; ch < CH; ++ch) acc[ch] = vzero<VEC>();
     spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc);
     spmm_store<VEC, LPR, CH>(acc, dst, d);
+}
+
+// Rows [row_begin, row_end) in slices of 32 floats, slice-major: every CU works on the same 128-B slice of the
+// gathered table at a time, so for a table of a few hundred thousand rows the hot rows of that slice stay in L2.
+template <int U>
+__global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ colidx,
+                                                          const float *__restrict__ vals, int64_t row_begin,
+                                                          int64_t row_end, int64_t row_blocks, int seg_len,
+                                                          const float *__restrict__ E, int64_t ldE,
+                                                          float *__restrict__ out, int64_t ldo)
+{
+    const int64_t slice = blockIdx.x / row_blocks;
+    const int64_t row = row_begin + ((int64_t)blockIdx.x % row_blocks) * 4 + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    const int64_t begin = rowptr[row], end = rowptr[row + 1];
+    if (end - begin > seg_len) return;   // cut row: produced from its segments
+    float4 acc[1];
+    acc[0] = vzero4();
+    spmm_accumulate<4, 8, 1, U>(colidx, vals, begin, end, E + slice * 32, ldE, 32, acc);
+    spmm_store<4, 8, 1>(acc, out + row * ldo + slice * 32, 32);
 }
 
 // cut rows: add their segments' partial sums in segment order (fixed order, no atomics)
@@ -494,10 +636,318 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Swept SpMM: the L2-blocked form for large matrices (same product LE = L.E, NGCF.py:130).
+//
+// Why: on a graph without locality the row-wise kernel above misses L2 on ~9 of 10 gathered rows and runs at
+// the chip's L2-miss rate (~8 TB/s of gathered bytes); rows served from L2 arrive 2-3x faster (measured with a
+// synchronised sliding window, profiles/r01_window_lab.txt).  Here the gathered table is swept in column blocks
+// that fit an XCD's 4 MiB L2 while every CU works on the same block, so a table row is fetched from memory
+// once per XCD and re-used from L2 by the other output rows of that XCD that need it.
+//
+// How: a persistent grid of 256 workgroups (one per CU, 1024 threads, 128 KiB of LDS).  Output rows are handed
+// to "owners"; an owner is a quarter-wave (16 lanes x 16 B = one 64-float slice of a row) that keeps up to 8
+// accumulator rows in LDS and walks its own edge list, which the host plan has sorted by (column block, row)
+// and balanced so that every owner has the same work in every block.  All owners start together and advance
+// at the same rate, so they sweep the table together without any cross-workgroup synchronisation (an owner
+// that gets ahead takes the L2 misses for the others, which slows it down again).  Correctness never depends on
+// that: an owner touches nothing but its own LDS rows and adds in list order (deterministic result).
+// Rows longer than the per-owner budget are dealt round-robin to several pieces whose partial sums are combined
+// by spmm_fixup_kernel in a fixed order.  A slice is 64 floats, so d must be a multiple of 64 (other widths use
+// the row-wise kernel); slices and owner rounds are walked one after the other inside the kernel.
+// ---------------------------------------------------------------------------------------------
+static const int kSweptRPO = 8;                  // accumulator rows per owner
+static const int kSweptOwnersPerWG = 64;         // 16 waves x 4 quarter-waves
+static const int kSweptWGs = 256;                // one 1024-thread workgroup per CU (128 KiB of LDS)
+static const int64_t kSweptUnused = INT64_MIN;
+
+static int32_t swept_block_cols()
+{
+    // columns per block: block bytes / (64 floats * 4 B); default 2 MiB of table slice per block
+    const char *e = getenv("NGCF_SWEPT_BLOCK_KB");
+    int64_t kb = e ? atoll(e) : 2048;
+    if (kb < 16) kb = 16;
+    return (int32_t)std::max<int64_t>(kb * 1024 / 256, 64);
+}
+
+template <typename F>
+static void parallel_for(int64_t n, F &&fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if (n < 64 || nt == 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t lo = t * chunk, hi = std::min<int64_t>(n, lo + chunk);
+        if (lo >= hi) break;
+        th.emplace_back([&fn, lo, hi]() { fn(lo, hi); });
+    }
+    for (auto &t : th) t.join();
+}
+
+static int build_swept_plan(ngcf_csr *c, hipStream_t stream)
+{
+    free_swept(c);
+    ngcf_csr::Swept &w = c->swept;
+    const int64_t n_rows = c->n_rows, nnz = c->nnz;
+    if (n_rows == 0) return NGCF_OK;
+    std::vector<int64_t> rp((size_t)n_rows + 1);
+    std::vector<int32_t> col((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
+    HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpyAsync(col.data(), c->colidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(val.data(), c->vals, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+
+    const int64_t per_round = (int64_t)kSweptOwnersPerWG * kSweptWGs;       // 8192 owners are resident at a time
+    const int64_t rounds = std::max<int64_t>(1, (n_rows + per_round * 13 - 1) / (per_round * 13));
+    const int64_t target = per_round * rounds;
+    int64_t T = std::max<int64_t>(64, (nnz + target - 1) / target);
+    w.block_cols = swept_block_cols();
+
+    // entries begin+off, begin+off+step, ... < end.  A long row is dealt out to its pieces round-robin so that every
+    // piece covers the whole column range evenly (a contiguous cut would pile one piece's work into a few blocks)
+    struct Piece { int64_t begin, end, dst, off, step; int64_t count() const { return end - begin <= off ? 0 : (end - begin - off + step - 1) / step; } };
+    std::vector<Piece> pieces;
+    std::vector<int32_t> heavy_row;
+    std::vector<int64_t> heavy_ptr, own_first;
+    int64_t n_partial = 0;
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        // 1) pieces: a row, or a <=T-entry cut of a long row (partial sums, combined in piece order)
+        pieces.clear();
+        heavy_row.clear();
+        heavy_ptr.assign(1, 0);
+        n_partial = 0;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t b = rp[r], e = rp[r + 1], len = e - b;
+            if (len <= T) {
+                pieces.push_back({b, e, r, 0, 1});
+            } else {
+                const int64_t k = (len + T - 1) / T;
+                heavy_row.push_back((int32_t)r);
+                for (int64_t j = 0; j < k; ++j) pieces.push_back({b, e, -1 - n_partial++, j, k});
+                heavy_ptr.push_back(n_partial);
+            }
+        }
+        // 2) owners: consecutive pieces until the entry budget or kSweptRPO rows are reached
+        own_first.assign(1, 0);
+        int64_t edges = 0;
+        int rows_in = 0;
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            const int64_t len = pieces[i].count();
+            if (rows_in == kSweptRPO || (rows_in > 0 && edges + len > T)) {
+                own_first.push_back((int64_t)i);
+                edges = 0;
+                rows_in = 0;
+            }
+            edges += len;
+            ++rows_in;
+        }
+        own_first.push_back((int64_t)pieces.size());
+        if ((int64_t)own_first.size() - 1 <= target) break;
+        T += std::max<int64_t>(1, T / 16);          // too many owners for the resident grid: raise the budget
+    }
+    const int64_t n_owners = (int64_t)own_first.size() - 1;
+    const int64_t n_owners_pad = align_up(n_owners, per_round);
+    const int64_t n_blocks = (c->n_cols + w.block_cols - 1) / w.block_cols;
+    std::vector<int64_t> own_ptr((size_t)n_owners_pad + 1, 0);
+    std::vector<int64_t> own_dst((size_t)n_owners_pad * kSweptRPO, kSweptUnused);
+    for (int64_t o = 0; o < n_owners; ++o) {
+        int64_t cnt = 0;
+        for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
+            cnt += pieces[i].count();
+            own_dst[(size_t)(o * kSweptRPO + (i - own_first[o]))] = pieces[i].dst;
+        }
+        if (cnt >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "swept plan: owner list too long");
+        own_ptr[(size_t)o + 1] = own_ptr[(size_t)o] + cnt;
+    }
+    for (int64_t o = n_owners; o < n_owners_pad; ++o) own_ptr[(size_t)o + 1] = own_ptr[(size_t)o];
+    // 3) per owner: stable counting sort of its entries by (column block, local row); block offsets kept
+    std::vector<int32_t> e_col((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> e_val((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<uint8_t> e_row((size_t)std::max<int64_t>(nnz, 1));
+    const int32_t bc = w.block_cols;
+    parallel_for(n_owners, [&](int64_t lo, int64_t hi) {
+        std::vector<int64_t> hist((size_t)n_blocks * kSweptRPO + 1);
+        for (int64_t o = lo; o < hi; ++o) {
+            std::fill(hist.begin(), hist.end(), 0);
+            for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
+                const int lr = (int)(i - own_first[o]);
+                for (int64_t x = pieces[i].begin + pieces[i].off; x < pieces[i].end; x += pieces[i].step)
+                    hist[(size_t)(col[x] / bc) * kSweptRPO + lr + 1]++;
+            }
+            for (size_t k = 1; k < hist.size(); ++k) hist[k] += hist[k - 1];
+            const int64_t base = own_ptr[(size_t)o];
+            for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
+                const int lr = (int)(i - own_first[o]);
+                for (int64_t x = pieces[i].begin + pieces[i].off; x < pieces[i].end; x += pieces[i].step) {
+                    const int64_t pos = base + hist[(size_t)(col[x] / bc) * kSweptRPO + lr]++;
+                    e_col[(size_t)pos] = col[x];
+                    e_val[(size_t)pos] = val[x];
+                    e_row[(size_t)pos] = (uint8_t)lr;
+                }
+            }
+        }
+    });
+    if (getenv("NGCF_SWEPT_DEBUG")) {
+        int64_t mx = 0, nz = 0;
+        for (int64_t o = 0; o < n_owners; ++o) {
+            mx = std::max(mx, own_ptr[(size_t)o + 1] - own_ptr[(size_t)o]);
+            nz += own_ptr[(size_t)o + 1] > own_ptr[(size_t)o];
+        }
+        fprintf(stderr, "[swept plan] rows %lld nnz %lld owners %lld (pad %lld, non-empty %lld) rounds %lld T %lld max/owner %lld "
+                        "pieces %zu partial %lld blocks %lld x %d cols\n", (long long)n_rows, (long long)nnz, (long long)n_owners,
+                (long long)n_owners_pad, (long long)nz, (long long)(n_owners_pad / per_round), (long long)T, (long long)mx,
+                pieces.size(), (long long)n_partial, (long long)n_blocks, (int)bc);
+    }
+    // 4) upload
+    w.n_owners = n_owners_pad;
+    w.n_rounds = (int32_t)(n_owners_pad / per_round);
+    w.n_blocks = (int32_t)n_blocks;
+    w.n_entries = nnz;
+    w.n_partial = n_partial;
+    w.n_heavy = (int64_t)heavy_row.size();
+    HIP_TRY(hipMalloc(&w.own_ptr, sizeof(int64_t) * own_ptr.size()));
+    HIP_TRY(hipMalloc(&w.own_dst, sizeof(int64_t) * own_dst.size()));
+    HIP_TRY(hipMalloc(&w.e_col, sizeof(int32_t) * e_col.size()));
+    HIP_TRY(hipMalloc(&w.e_val, sizeof(float) * e_val.size()));
+    HIP_TRY(hipMalloc(&w.e_row, e_row.size()));
+    HIP_TRY(hipMemcpyAsync(w.own_ptr, own_ptr.data(), sizeof(int64_t) * own_ptr.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.own_dst, own_dst.data(), sizeof(int64_t) * own_dst.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.e_col, e_col.data(), sizeof(int32_t) * e_col.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.e_val, e_val.data(), sizeof(float) * e_val.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.e_row, e_row.data(), e_row.size(), hipMemcpyHostToDevice, stream));
+    if (w.n_heavy > 0) {
+        HIP_TRY(hipMalloc(&w.heavy_row, sizeof(int32_t) * heavy_row.size()));
+        HIP_TRY(hipMalloc(&w.heavy_seg_ptr, sizeof(int64_t) * heavy_ptr.size()));
+        HIP_TRY(hipMemcpyAsync(w.heavy_row, heavy_row.data(), sizeof(int32_t) * heavy_row.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(w.heavy_seg_ptr, heavy_ptr.data(), sizeof(int64_t) * heavy_ptr.size(), hipMemcpyHostToDevice, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return NGCF_OK;
+}
+
+// value of lane U of this lane's 16-lane row (DPP row_newbcast: one VALU op, no LDS round trip)
+template <int U> __device__ inline int row_bcast(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false);
+}
+template <int U> __device__ inline float row_bcast(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + U, 0xf, 0xf, false));
+}
+
+// add a 16-lane x float4 accumulator into the owner's LDS row
+__device__ inline void swept_flush(float *__restrict__ rowp, float4 a)
+{
+    float4 *p = reinterpret_cast<float4 *>(rowp);
+    float4 t = *p;
+    t.x += a.x;
+    t.y += a.y;
+    t.z += a.z;
+    t.w += a.w;
+    *p = t;
+}
+
+#ifdef NGCF_SWEPT_STAMPS
+// diagnostic build only (tools/): cycle stamps of one quarter-wave per workgroup, summed per phase
+#define NGCF_STAMP(t) unsigned long long t = __builtin_readcyclecounter()
+#define NGCF_STAMP_ADD(i, t) stamp_sum[i] += __builtin_readcyclecounter() - t
+#define NGCF_STAMP_USE(x) asm volatile("" ::"v"(x))
+#else
+#define NGCF_STAMP(t)
+#define NGCF_STAMP_ADD(i, t)
+#define NGCF_STAMP_USE(x)
+#endif
+
+#define NGCF_SWEPT_THREADS (kSweptOwnersPerWG * 16)
+
+// One chunk of up to 16 list entries of one owner: all 16 gathers are issued before the first is consumed;
+// consecutive entries of one row are summed in registers and added to the owner's LDS row when the row changes.
+template <bool FULL>
+__device__ inline void swept_chunk(const int32_t *__restrict__ e_col, const float *__restrict__ e_val,
+                                   const uint8_t *__restrict__ e_row, int64_t base, int cnt, int l,
+                                   const float *__restrict__ Es, int64_t ldE, float *__restrict__ myacc, int &cur,
+                                   float4 &a)
+{
+    int c = 0, r = 0;
+    float v = 0.f;
+    if (FULL || l < cnt) {
+        c = e_col[base + l];
+        v = e_val[base + l];
+        r = e_row[base + l];
+    }
+    if (!FULL) {   // idle slots re-read the chunk's first row (an L2 hit); DPP needs its source lane active
+        const int c0 = row_bcast<0>(c);
+        c = l < cnt ? c : c0;
+    }
+    float4 x[16];
+#define NGCF_GATHER(u) x[u] = *reinterpret_cast<const float4 *>(Es + (int64_t)row_bcast<u>(c) * ldE);
+    NGCF_GATHER(0) NGCF_GATHER(1) NGCF_GATHER(2) NGCF_GATHER(3) NGCF_GATHER(4) NGCF_GATHER(5) NGCF_GATHER(6) NGCF_GATHER(7)
+    NGCF_GATHER(8) NGCF_GATHER(9) NGCF_GATHER(10) NGCF_GATHER(11) NGCF_GATHER(12) NGCF_GATHER(13) NGCF_GATHER(14) NGCF_GATHER(15)
+#undef NGCF_GATHER
+#define NGCF_ACCUM(u)                                   \
+    if (FULL || u < cnt) {                              \
+        const int rr = row_bcast<u>(r);                 \
+        if (rr != cur) {                                \
+            swept_flush(myacc + cur * 64, a);           \
+            a = vzero4();                               \
+            cur = rr;                                   \
+        }                                               \
+        a = vfma(row_bcast<u>(v), x[u], a);             \
+    }
+    NGCF_ACCUM(0) NGCF_ACCUM(1) NGCF_ACCUM(2) NGCF_ACCUM(3) NGCF_ACCUM(4) NGCF_ACCUM(5) NGCF_ACCUM(6) NGCF_ACCUM(7)
+    NGCF_ACCUM(8) NGCF_ACCUM(9) NGCF_ACCUM(10) NGCF_ACCUM(11) NGCF_ACCUM(12) NGCF_ACCUM(13) NGCF_ACCUM(14) NGCF_ACCUM(15)
+#undef NGCF_ACCUM
+}
+
+__global__ __launch_bounds__(NGCF_SWEPT_THREADS) void spmm_swept_kernel(
+    const int64_t *__restrict__ own_ptr, const int32_t *__restrict__ e_col, const float *__restrict__ e_val,
+    const uint8_t *__restrict__ e_row, const int64_t *__restrict__ own_dst, int n_rounds, int n_slices,
+    const float *__restrict__ E, int64_t ldE, float *__restrict__ out, int64_t ldo, float *__restrict__ partial, int dp)
+{
+    __shared__ float acc_lds[kSweptOwnersPerWG * kSweptRPO * 64];   // 128 KiB: 64 owners x 8 rows x 64 floats
+    const int q = threadIdx.x >> 4;          // owner slot in the workgroup
+    const int l = threadIdx.x & 15;          // lane in the quarter-wave
+    float *myacc = acc_lds + q * (kSweptRPO * 64) + l * 4;
+    for (int slice = 0; slice < n_slices; ++slice) {
+        const float *Es = E + slice * 64 + l * 4;
+        for (int round = 0; round < n_rounds; ++round) {
+            const int64_t owner = ((int64_t)round * gridDim.x + blockIdx.x) * kSweptOwnersPerWG + q;
+#pragma unroll
+            for (int r = 0; r < kSweptRPO; ++r) *reinterpret_cast<float4 *>(myacc + r * 64) = vzero4();
+            const int64_t beg = own_ptr[owner], end = own_ptr[owner + 1];
+            int cur = 0;
+            float4 a = vzero4();
+            int64_t base = beg;
+            for (; base + 16 <= end; base += 16) swept_chunk<true>(e_col, e_val, e_row, base, 16, l, Es, ldE, myacc, cur, a);
+            if (base < end) swept_chunk<false>(e_col, e_val, e_row, base, (int)(end - base), l, Es, ldE, myacc, cur, a);
+            swept_flush(myacc + cur * 64, a);
+            // write the owner's rows (its own LDS rows only: no barrier needed)
+#pragma unroll 1
+            for (int r = 0; r < kSweptRPO; ++r) {
+                const int64_t dst = own_dst[owner * kSweptRPO + r];
+                if (dst == kSweptUnused) continue;
+                float *p = dst >= 0 ? out + dst * ldo : partial + (-1 - dst) * (int64_t)dp;
+                *reinterpret_cast<float4 *>(p + slice * 64 + l * 4) = *reinterpret_cast<const float4 *>(myacc + r * 64);
+            }
+        }
+    }
+}
+
 extern "C" int64_t ngcf_spmm_workspace_bytes(const ngcf_csr_t *c, int d)
 {
     if (!c || d <= 0) return -1;
-    return align_up(c->n_seg * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
+    const int64_t n_part = std::max(c->n_seg, c->swept.n_partial);
+    return align_up(n_part * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,14 +1014,36 @@ int launch_spmm(const SpmmArgs &a)
 {
     const ngcf_csr *c = a.c;
     const int64_t seg_blocks = (c->n_seg + 3) / 4;
-    const int64_t blocks = seg_blocks + (c->n_rows + 3) / 4;
-    if (blocks == 0) return NGCF_OK;
-    if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+    // d-slicing of the sliceable row groups needs 16-byte slices of 32 floats
+    const bool can_slice = VEC == 4 && a.d % 32 == 0 && a.d >= 64 && c->mode != 1 && !getenv("NGCF_NO_SLICING");
     prof_mark(a.stream, 0);
-    spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
-        c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, a.E,
-        a.ldE, a.d, a.out, a.ldo, a.partial, a.dp);
-    LAUNCH_CHECK();
+    bool seg_done = seg_blocks == 0;
+    for (size_t g = 0; g <= c->groups.size(); ++g) {
+        const bool last = g == c->groups.size();
+        if (last && seg_done) break;
+        if (!last && can_slice && c->groups[g].sliceable) {
+            const int64_t rb = (c->groups[g].end - c->groups[g].begin + 3) / 4;
+            const int64_t blocks = rb * (a.d / 32);
+            if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+            spmm_sliced_kernel<8><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(c->rowptr, c->colidx, c->vals, c->groups[g].begin,
+                                                                               c->groups[g].end, rb, c->seg_len, a.E, a.ldE,
+                                                                               a.out, a.ldo);
+            LAUNCH_CHECK();
+            continue;
+        }
+        // unsliced group; the segments of the cut rows ride in front of the first such launch
+        const int64_t rbeg = last ? 0 : c->groups[g].begin, rend = last ? 0 : c->groups[g].end;
+        const int64_t sb = seg_done ? 0 : seg_blocks;
+        const int64_t blocks = sb + (rend - rbeg + 3) / 4;
+        if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+        if (blocks > 0) {
+            spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
+                c->rowptr, c->colidx, c->vals, rbeg, rend, c->seg_row, c->seg_begin, seg_done ? 0 : c->n_seg, sb, c->seg_len,
+                a.E, a.ldE, a.d, a.out, a.ldo, a.partial, a.dp);
+            LAUNCH_CHECK();
+        }
+        seg_done = true;
+    }
     prof_mark(a.stream, 1);
     if (c->n_heavy > 0) {
         const int64_t fb = (c->n_heavy + 3) / 4;
@@ -599,6 +1071,26 @@ static int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, 
     }
     SpmmArgs a{c, E, ldE, d, out, ldo, partial, dp, stream};
     const bool vec = (d % 4 == 0) && (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
+    const ngcf_csr::Swept &w = c->swept;
+    if (vec && d % 64 == 0 && w.n_owners > 0 && c->mode == 2) {
+        if (w.n_partial > 0 && !partial) {
+            const int64_t need = ngcf_spmm_workspace_bytes(c, d);
+            if (!workspace || workspace_bytes < need)
+                return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+            partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+        }
+        prof_mark(stream, 0);
+        spmm_swept_kernel<<<dim3(kSweptWGs), NGCF_SWEPT_THREADS, 0, stream>>>(w.own_ptr, w.e_col, w.e_val, w.e_row, w.own_dst,
+                                                                              w.n_rounds, d / 64, E, ldE, out, ldo, partial, dp);
+        LAUNCH_CHECK();
+        prof_mark(stream, 1);
+        if (w.n_heavy > 0) {
+            spmm_fixup_kernel<4><<<dim3((unsigned)((w.n_heavy + 3) / 4)), 256, 0, stream>>>(
+                w.heavy_row, w.heavy_seg_ptr, w.n_heavy, partial, dp, d, out, ldo);
+            LAUNCH_CHECK();
+        }
+        return NGCF_OK;
+    }
     if (vec) {
         const int nq = d / 4;
         if (nq <= 8) return launch_spmm<4, 8, 1, 4>(a);

@@ -108,6 +108,10 @@ class LaplacianCSR:
     def plan(self, seg_len: int):
         _lib.check(_lib.load().ngcf_csr_plan(self._h, int(seg_len), _stream()))
 
+    def set_mode(self, mode: int):
+        """0 automatic, 1 row-wise gather kernel only, 2 L2-swept kernel whenever the width is a multiple of 64."""
+        _lib.check(_lib.load().ngcf_csr_set_mode(self._h, int(mode), _stream()))
+
     @property
     def n_segments(self) -> int:
         return int(_lib.load().ngcf_csr_n_segments(self._h))

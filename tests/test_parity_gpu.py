@@ -156,11 +156,46 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
         got = eng.spmm(csr, Ed).cpu().numpy()
         np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
         assert np.all(got[[0, 1, 500]] == 0)                      # empty rows are written as zeros
+    if d % 64 == 0:
+        # the experimental L2-swept kernel (opt-in); rows longer than the per-owner budget are dealt to several
+        # pieces -> partial sums + fix-up
+        csr.set_mode(2)
+        got = eng.spmm(csr, Ed).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
+        assert np.all(got[[0, 1, 500]] == 0)
+        got2 = eng.spmm(csr, Ed).cpu().numpy()
+        assert np.array_equal(got, got2)                          # deterministic: fixed summation order
+        csr.set_mode(1)
     # a column-sliced (strided) operand, as the engine uses for all_E blocks
     big = torch.zeros((n_cols, d + 24), device=dev)
     big[:, 8:8 + d] = Ed
     got = eng.spmm(csr, big[:, 8:8 + d]).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
+    """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the opt-in
+    swept kernel and the plain row-wise kernel must give the same product."""
+    pkg = _pkg()
+    eng = pkg.engine
+    coo = pkg.graphs.synthetic_bipartite(150000, 12000, 2600000, seed=33, device=dev)
+    N = coo["n_user"] + coo["n_item"]
+    csr = eng.LaplacianCSR.from_coo(coo["rows"], coo["cols"], coo["vals"], N, N)
+    X = torch.randn((N, d), generator=torch.Generator(device=dev).manual_seed(d), device=dev)
+    auto = eng.spmm(csr, X)                    # mode 0: row groups, sliceable ones d-sliced
+    csr.set_mode(2)
+    swept = eng.spmm(csr, X)
+    csr.set_mode(1)
+    rowwise = eng.spmm(csr, X)                 # mode 1: no slicing
+    scale = float(rowwise.abs().max())
+    assert float((swept - rowwise).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert float((auto - rowwise).abs().max()) <= 2e-6 * max(scale, 1.0)
+    rows = torch.cat([torch.randint(0, N, (64,), device=dev), torch.tensor([coo["n_user"], coo["n_user"] + 1], device=dev)])
+    rp = torch.searchsorted(coo["rows"], torch.stack([rows, rows + 1]))
+    for r, (lo, hi) in zip(rows.tolist(), rp.T.tolist()):
+        want = (coo["vals"][lo:hi].double()[:, None] * X[coo["cols"][lo:hi]].double()).sum(0)
+        np.testing.assert_allclose(swept[r].cpu().numpy(), want.cpu().numpy(), atol=ATOL, rtol=RTOL)
 
 
 def test_spmm_unsorted_and_duplicate_coo(dev, oracle_clib):
