@@ -1127,19 +1127,23 @@ extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ld
 #define NGCF_DC 16
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers inside lambdas
 
 __global__ void pack_weights_kernel(const float *__restrict__ W1, const float *__restrict__ b1,
                                     const float *__restrict__ W2, const float *__restrict__ b2, int d_in, int d_out,
-                                    int n_chunks, int DOP, float *__restrict__ Wt, float *__restrict__ bias2)
+                                    int n_chunks, int DOP, int NT, float *__restrict__ Wt, float *__restrict__ bias2)
 {
+    // Wt[chunk][kl][cw][j][t] = weight of output column (cw*NT + t)*32 + j: a lane reads its NT tile values at once
     const int total = n_chunks * NGCF_KC * DOP;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int j = i % DOP;
+        const int within = i % DOP;
+        const int t = within % NT, j = (within / NT) % 32, cw = within / (NT * 32);
+        const int oc = (cw * NT + t) * 32 + j;
         const int k = i / DOP;
         const int chunk = k / NGCF_KC, kl = k % NGCF_KC;
         const int col = chunk * NGCF_DC + (kl % NGCF_DC);
         float w = 0.f;
-        if (j < d_out && col < d_in) w = (kl < NGCF_DC ? W1 : W2)[(int64_t)j * d_in + col];
+        if (oc < d_out && col < d_in) w = (kl < NGCF_DC ? W1 : W2)[(int64_t)oc * d_in + col];
         Wt[i] = w;
     }
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < DOP; j += gridDim.x * blockDim.x)
@@ -1168,9 +1172,13 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
 {
     constexpr int BM = 32 * RW;
     constexpr int WCOLS = 32 * NT * CW;      // == DOP
-    constexpr int XLD = NGCF_KC + 1;         // +1 pad: conflict-free column reads
-    __shared__ float Xs[BM * XLD];
-    __shared__ float Ws[NGCF_KC * WCOLS];
+    constexpr int XLD = NGCF_KC + 4;         // 36: rows stay 16-B aligned and b128 column reads are conflict-free
+    constexpr bool DB = WCOLS <= 128;        // double-buffered LDS (one barrier per chunk) where two blocks still fit a CU
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int RR = (BM + 63) / 64;       // X rows staged per thread
+    constexpr int WN = (NGCF_KC * WCOLS / 4) / 256;   // W float4s staged per thread
+    __shared__ float Xs[NBUF * BM * XLD];
+    __shared__ float Ws[NBUF * NGCF_KC * WCOLS];
     __shared__ float ssq[BM * CW];
 
     const int tid = threadIdx.x;
@@ -1188,58 +1196,90 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
     // staging roles: 4 lanes x 4 columns cover the 16 input columns of a chunk for one row
     const int sq = tid & 3;
     const int sr = tid >> 2;   // 0..63
+    f32x4 xle[RR], xe[RR], wreg[WN];
 
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        // ---- stage X chunk: rows sr, sr+64, ... ; columns chunk*16 + sq*4 .. +4
+    auto load_chunk = [&](int chunk) {       // global -> registers
         const int c0 = chunk * NGCF_DC + sq * 4;
 #pragma unroll
-        for (int rr = 0; rr < (BM + 63) / 64; ++rr) {
+        for (int rr = 0; rr < RR; ++rr) {
+            const int r = sr + rr * 64;
+            float le[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+            const int64_t grow = row0 + r;
+            if (r < BM && grow < n_rows) {
+                if (ALIGNED && c0 + 4 <= d_in) {
+                    const float4 a = *reinterpret_cast<const float4 *>(LE + grow * ldLE + c0);
+                    const float4 b = *reinterpret_cast<const float4 *>(Es + grow * ldE + c0);
+                    le[0] = a.x; le[1] = a.y; le[2] = a.z; le[3] = a.w;
+                    e[0] = b.x; e[1] = b.y; e[2] = b.z; e[3] = b.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < d_in) {
+                            le[q] = LE[grow * ldLE + c0 + q];
+                            e[q] = Es[grow * ldE + c0 + q];
+                        }
+                }
+            }
+            xle[rr] = f32x4{le[0], le[1], le[2], le[3]};
+            xe[rr] = f32x4{e[0], e[1], e[2], e[3]};
+        }
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) wreg[i] = src[tid + i * 256];
+    };
+    auto store_chunk = [&](int buf) {        // registers -> LDS: (LE + E) feeds W1, (LE * E) feeds W2
+        float *X = Xs + buf * (BM * XLD);
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
             const int r = sr + rr * 64;
             if (r < BM) {
-                float le[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
-                const int64_t grow = row0 + r;
-                if (grow < n_rows) {
-                    if (ALIGNED && c0 + 4 <= d_in) {
-                        const float4 a = *reinterpret_cast<const float4 *>(LE + grow * ldLE + c0);
-                        const float4 b = *reinterpret_cast<const float4 *>(Es + grow * ldE + c0);
-                        le[0] = a.x; le[1] = a.y; le[2] = a.z; le[3] = a.w;
-                        e[0] = b.x; e[1] = b.y; e[2] = b.z; e[3] = b.w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (c0 + q < d_in) {
-                                le[q] = LE[grow * ldLE + c0 + q];
-                                e[q] = Es[grow * ldE + c0 + q];
-                            }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    Xs[r * XLD + sq * 4 + q] = le[q] + e[q];                 // (LE + E)   -> W1
-                    Xs[r * XLD + NGCF_DC + sq * 4 + q] = le[q] * e[q];       // (LE * E)   -> W2
-                }
+                const f32x4 a = xle[rr], b = xe[rr];
+                *reinterpret_cast<f32x4 *>(X + r * XLD + sq * 4) = a + b;
+                *reinterpret_cast<f32x4 *>(X + r * XLD + NGCF_DC + sq * 4) = a * b;
             }
         }
-        // ---- stage W chunk: KC x WCOLS contiguous floats
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
-            float4 *dst = reinterpret_cast<float4 *>(Ws);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Ws + buf * (NGCF_KC * WCOLS));
 #pragma unroll
-            for (int i = 0; i < (NGCF_KC * WCOLS / 4) / 256; ++i) dst[tid + i * 256] = src[tid + i * 256];
-        }
-        __syncthreads();
-        // ---- MFMA over the 32 k-values of the chunk
-#pragma unroll 4
-        for (int s = 0; s < NGCF_KC / 2; ++s) {
-            const int k = 2 * s + lh;
-            const float a = Xs[(rw * 32 + li) * XLD + k];
+        for (int i = 0; i < WN; ++i) dst[tid + i * 256] = wreg[i];
+    };
+    auto compute_chunk = [&](int buf) {      // 32 k-values: 4 blocks of (one b128 A read, 4 x NT-wide B reads, 4*NT MFMAs)
+        const float *X = Xs + buf * (BM * XLD) + (rw * 32 + li) * XLD + lh * 4;
+        const float *W = Ws + buf * (NGCF_KC * WCOLS) + cw * (32 * NT) + li * NT;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = Ws[k * WCOLS + (cw * NT + t) * 32 + li];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-            }
+        for (int kb = 0; kb < NGCF_KC / 8; ++kb) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(X + kb * 8);
+#define NGCF_KSTEP(sx, aval)                                                                                   \
+    {                                                                                                          \
+        const float *wk = W + (kb * 8 + lh * 4 + sx) * WCOLS;                                                  \
+        float bv[NT];                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) bv[t] = wk[t];                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                         \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[t], acc[t], 0, 0, 0);                       \
+    }
+            NGCF_KSTEP(0, a4.x) NGCF_KSTEP(1, a4.y) NGCF_KSTEP(2, a4.z) NGCF_KSTEP(3, a4.w)
+#undef NGCF_KSTEP
         }
+    };
+
+    if (DB) {
+        load_chunk(0);
+        store_chunk(0);
         __syncthreads();
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const bool more = chunk + 1 < n_chunks;
+            if (more) load_chunk(chunk + 1);        // global loads fly under the MFMAs
+            compute_chunk(chunk & 1);
+            if (more) store_chunk((chunk + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            load_chunk(chunk);
+            store_chunk(0);
+            __syncthreads();
+            compute_chunk(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias, LeakyReLU, dropout, row sum of squares
@@ -1369,7 +1409,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const int n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
     float *Wt = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
     float *bias2 = Wt + (int64_t)n_chunks * NGCF_KC * dop;
-    pack_weights_kernel<<<64, 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, Wt, bias2);
+    pack_weights_kernel<<<64, 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, dop <= 128 ? dop / 32 : 4, Wt, bias2);
     LAUNCH_CHECK();
     const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
 #define NGCF_DENSE(RW, CW, NT) \
