@@ -148,6 +148,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
     for _ in range(args.warmup):
         loss = step()
     barrier()

@@ -168,6 +168,30 @@ int ngcf_bpr_fused_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, c
                        int D, float weight_decay, float batch_size, float *loss,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- backward pass (experimental; `loss.backward()` of experiment.py:57) -------------------- */
+/* The two plain GEMMs of a layer's backward (dM.[W1|W2] and dM^T.[S|P]) are library GEMMs issued by the host
+ * mirror; the entry points below are everything around them.  L^T.dLE re-uses ngcf_spmm_csr_f32 on the CSR of L^T. */
+/* du/dp/dn of the BPR loss (bprloss.py:15-22) times the upstream scalar *grad_out (device). */
+int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, const float *n, int64_t Bn, int D,
+                          float weight_decay, float batch_size, const float *grad_out, float *du, float *dp,
+                          float *dn, void *stream);
+/* Backward of the row gathers (NGCF.py:151-155): G[row_off + idx[b], :] += g[b, :]; duplicates add up. */
+int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, int64_t B, int64_t row_off,
+                              int64_t n_idx_rows, const float *g, int64_t ldg, void *stream);
+/* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block),
+ * dC (gradient of the carry from the next layer, may be NULL) and the saved carry C. */
+int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
+                           int64_t n_rows, int d, float leaky_slope, float drop_p, uint64_t drop_seed, float *dM,
+                           int64_t ldm, void *stream);
+/* SP[n_rows, 2d] = [LE + E | LE * E], the forward GEMM operand (NGCF.py:131-136), needed for dW1/dW2. */
+int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ldE, int64_t n_rows, int d, float *SP,
+                       void *stream);
+/* dSP[n_rows, 2d] = dM.[W1 | W2]  ->  dLE = dS + dP*E,  dE_direct = dS + dP*LE  (both [n_rows, d] contiguous). */
+int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
+                               int64_t n_rows, int d, float *dLE, float *dE, void *stream);
+/* out[r, 0:d] += add[r, 0:d] */
+int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream);
+
 /* ---- multi-GPU row partition (new design; host-only helper) --------------- */
 /*
  * Cut rows [row_begin, row_end) into `world` contiguous ranges of roughly equal stored-entry

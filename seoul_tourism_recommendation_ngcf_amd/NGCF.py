@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as _eng
-from .autograd import propagate_with_grad
+from .autograd import GatherTriple, propagate_with_grad
 
 
 class NGCF(nn.Module):
@@ -75,6 +75,7 @@ class NGCF(nn.Module):
         self.node_dropout_mode = "reference"
         self.all_users_emb = None
         self.all_items_emb = None
+        self._all_E = None
 
     # ------------------------------------------------------------------------------------
     # engine plumbing
@@ -112,6 +113,22 @@ class NGCF(nn.Module):
             self._csr_cache[key] = csr
         return csr
 
+    def laplacian_csr_t(self, year_idx: int) -> "_eng.LaplacianCSR":
+        """CSR of `lap_list[year_idx]` transposed (for `L^T . dLE` in the backward), built on first use."""
+        dev = self._dev()
+        L = self.lap_list[year_idx]
+        key = ("T", year_idx, id(L), str(dev))
+        csr = self._csr_cache.get(key)
+        if csr is None:
+            csr = self._transposed_csr(L._indices().to(dev), L._values().to(device=dev, dtype=torch.float32))
+            self._csr_cache[key] = csr
+        return csr
+
+    def _transposed_csr(self, idx: torch.Tensor, val: torch.Tensor) -> "_eng.LaplacianCSR":
+        N = self.n_user + self.n_item
+        order = torch.sort(idx[1], stable=True).indices          # by column = row of L^T, original order kept inside
+        return _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N)
+
     def _layer_params(self):
         return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],
                 [l.weight for l in self.w2_list], [l.bias for l in self.w2_list])
@@ -128,13 +145,15 @@ class NGCF(nn.Module):
         idx = L._indices().to(dev)
         val = L._values().to(device=dev, dtype=torch.float32)
         N = self.n_user + self.n_item
-        out = []
+        out, kept = [], []
         for _ in range(self.n_layer):
             mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
                                                p=self.node_dropout, training=True).type(torch.bool).to(dev)
             idx, val = idx[:, mask], val[mask]
             out.append(_eng.LaplacianCSR.from_coo(idx[0], idx[1], val, N, N))
-        return out
+            kept.append((idx, val))
+        # the thinned matrices are not symmetric: their transposes are built only if a backward needs them
+        return out, (lambda: [self._transposed_csr(i, v) for i, v in kept])
 
     # ------------------------------------------------------------------------------------
     # propagation (NGCF.py:120-149)
@@ -142,7 +161,11 @@ class NGCF(nn.Module):
     def propagate(self, year_idx: int = 0, node_flag: bool = False) -> torch.Tensor:
         """all_E = [E0 | norm(E1) | ... | norm(En)]  for the current parameters; sets all_users_emb/all_items_emb."""
         self._dev()
-        csrs = self._dropped_csr_list(year_idx) if node_flag else [self.laplacian_csr(year_idx)] * self.n_layer
+        if node_flag:
+            csrs, csrs_t_fn = self._dropped_csr_list(year_idx)
+        else:
+            csrs = [self.laplacian_csr(year_idx)] * self.n_layer
+            csrs_t_fn = lambda: [self.laplacian_csr_t(year_idx)] * self.n_layer   # noqa: E731
         drop = [0.0] * self.n_layer
         if self.training and self.mess_dropout is not None:            # nn.Dropout follows train()/eval(), NGCF.py:142
             drop = [float(p) for p in self.mess_dropout[:self.n_layer]]
@@ -150,8 +173,9 @@ class NGCF(nn.Module):
         if any(p > 0 for p in drop):
             seeds = [int(s) for s in torch.randint(0, 2 ** 62, (self.n_layer,), dtype=torch.int64)]
         w1, b1, w2, b2 = self._layer_params()
-        all_E = propagate_with_grad(self, csrs, self.user_embedding.weight, self.item_embedding.weight,
+        all_E = propagate_with_grad(self, csrs, csrs_t_fn, self.user_embedding.weight, self.item_embedding.weight,
                                     w1, b1, w2, b2, drop, seeds)
+        self._all_E = all_E
         self.all_users_emb = all_E[:self.n_user, :]                    # NGCF.py:148-149
         self.all_items_emb = all_E[self.n_user:, :]
         return all_E
@@ -178,14 +202,20 @@ class NGCF(nn.Module):
         year_idx = int(year.min().item() % 18) if year.numel() else 0   # == year.unique()[0] % 18, NGCF.py:117
         self.propagate(year_idx, bool(node_flag))
 
-        u_idx = u_id.to(device=dev, dtype=torch.int64)
-        p_idx = pos_item.to(device=dev, dtype=torch.int64)
-        u_embeddings = self._gather(self.all_users_emb, u_idx, status)          # NGCF.py:151
-        pos_i_embeddings = self._gather(self.all_items_emb, p_idx, status)      # NGCF.py:152
+        u_idx = u_id.to(device=dev, dtype=torch.int64).contiguous()
+        p_idx = pos_item.to(device=dev, dtype=torch.int64).contiguous()
+        n_idx = neg_item.to(device=dev, dtype=torch.int64).contiguous() if len(neg_item) > 0 else None
         neg_i_embeddings = torch.empty(0)                                       # NGCF.py:153
-        if len(neg_item) > 0:
-            n_idx = neg_item.to(device=dev, dtype=torch.int64)
-            neg_i_embeddings = self._gather(self.all_items_emb, n_idx, status)  # NGCF.py:155
+        if self._all_E.requires_grad:
+            outs = GatherTriple.apply(self._all_E, self.n_user, status, u_idx, p_idx, n_idx)
+            u_embeddings, pos_i_embeddings = outs[0], outs[1]
+            if n_idx is not None:
+                neg_i_embeddings = outs[2]
+        else:
+            u_embeddings = _eng.gather_rows(self.all_users_emb, u_idx, status)          # NGCF.py:151
+            pos_i_embeddings = _eng.gather_rows(self.all_items_emb, p_idx, status)      # NGCF.py:152
+            if n_idx is not None:
+                neg_i_embeddings = _eng.gather_rows(self.all_items_emb, n_idx, status)  # NGCF.py:155
         if self.check_indices:
             if int(status.item()) != 0:
                 status.zero_()
@@ -193,6 +223,3 @@ class NGCF(nn.Module):
         del keep
         return u_embeddings, pos_i_embeddings, neg_i_embeddings
 
-    def _gather(self, table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
-        from .autograd import gather_with_grad
-        return gather_with_grad(table, idx, status)

@@ -1,22 +1,26 @@
-"""Forward drivers of the propagation engine (and the autograd seam for the backward row).
+"""Forward drivers of the propagation engine and the autograd seam for training.
 
-`propagate_forward` issues the HIP layer kernels for NGCF.py:120-147.  Round 1 ships the forward
-path only: outputs carry no grad_fn (the backward pass, is the next row),
-which is what `Experiment.eval` (experiment.py:66-119) and demo.py need.
+`propagate_forward` issues the HIP layer kernels for NGCF.py:120-147 (inference path, nothing saved).
+`Propagate` / `GatherTriple` / `BPRLoss` are `torch.autograd.Function`s so that `loss.backward()`
+(experiment.py:57) reaches every parameter: their backward runs the HIP kernels of the "backward pass" section
+of include/ngcf_hip.h plus two plain library GEMMs per layer (`dM @ [W1|W2]`, `dM^T @ [S|P]`) and `L^T . dLE`
+on the SpMM kernel.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Optional, Sequence
 
 import torch
 
+from . import _lib
 from . import engine as _eng
+from .engine import _ptr, _row_major_ld, _stream
 
 
 def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.Tensor, item_w: torch.Tensor,
-                      w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int],
-                      keep_carries: bool = False):
-    """all_E [N, D] = [E0 | norm(E1) | ... | norm(En)] (NGCF.py:120-147).
+                      w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int]):
+    """all_E [N, D] = [E0 | norm(E1) | ... | norm(En)] (NGCF.py:120-147), inference path.
 
     E0 is written once into its column block of all_E (this is both the `cat` of NGCF.py:120 and
     the one of NGCF.py:147); each layer reads its input in place and writes its normalised output
@@ -34,33 +38,189 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
     _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
     prev = all_E[:, :d0]
     off = d0
-    carries: List[Optional[torch.Tensor]] = []
     for k in range(n_layer):
         d_out = widths[k + 1]
-        last = k == n_layer - 1
         carry = None
-        if not last or keep_carries:
-            if keep_carries:
-                carry = torch.empty((N, d_out), dtype=torch.float32, device=dev)
-            else:
-                buf = owner._carry[k % 2]
-                if buf is None or buf.device != dev or tuple(buf.shape) != (N, d_out):
-                    buf = torch.empty((N, d_out), dtype=torch.float32, device=dev)
-                    owner._carry[k % 2] = buf
-                carry = buf
+        if k < n_layer - 1:
+            buf = owner._carry[k % 2]
+            if buf is None or buf.device != dev or tuple(buf.shape) != (N, d_out):
+                buf = torch.empty((N, d_out), dtype=torch.float32, device=dev)
+                owner._carry[k % 2] = buf
+            carry = buf
         _eng.layer_fused(csrs[k], prev, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(),
                          carry, all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
-        carries.append(carry)
         prev = carry
         off += d_out
-    return (all_E, carries) if keep_carries else all_E
+    return all_E
 
 
-def propagate_with_grad(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds) -> torch.Tensor:
-    with torch.no_grad():
-        return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds)
+# ------------------------------------------------------------------------------------------------
+# thin wrappers of the backward entry points
+# ------------------------------------------------------------------------------------------------
+def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed):
+    lib = _lib.load()
+    n_rows, d = Cc.shape
+    dM = torch.empty((n_rows, d), dtype=torch.float32, device=Cc.device)
+    with torch.cuda.device(Cc.device):
+        _lib.check(lib.ngcf_layer_bwd_pre_f32(_ptr(dN), _row_major_ld(dN, "dN"), _ptr(dC),
+                                              0 if dC is None else _row_major_ld(dC, "dC"), _ptr(Cc),
+                                              _row_major_ld(Cc, "C"), n_rows, d, leaky, float(drop_p), int(seed),
+                                              _ptr(dM), d, _stream()))
+    return dM
 
 
-def gather_with_grad(table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
-    with torch.no_grad():
-        return _eng.gather_rows(table, idx, status)
+def _sp_concat(LE, E):
+    lib = _lib.load()
+    n_rows, d = LE.shape
+    SP = torch.empty((n_rows, 2 * d), dtype=torch.float32, device=LE.device)
+    with torch.cuda.device(LE.device):
+        _lib.check(lib.ngcf_sp_concat_f32(_ptr(LE), _row_major_ld(LE, "LE"), _ptr(E), _row_major_ld(E, "E"), n_rows, d,
+                                          _ptr(SP), _stream()))
+    return SP
+
+
+def _bwd_combine(dSP, LE, E):
+    lib = _lib.load()
+    n_rows, d = LE.shape
+    dLE = torch.empty((n_rows, d), dtype=torch.float32, device=LE.device)
+    dE = torch.empty((n_rows, d), dtype=torch.float32, device=LE.device)
+    with torch.cuda.device(LE.device):
+        _lib.check(lib.ngcf_layer_bwd_combine_f32(_ptr(dSP), _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E),
+                                                  _row_major_ld(E, "E"), n_rows, d, _ptr(dLE), _ptr(dE), _stream()))
+    return dLE, dE
+
+
+def _add_rows(out, add):
+    lib = _lib.load()
+    with torch.cuda.device(out.device):
+        _lib.check(lib.ngcf_add_rows_f32(_ptr(out), _row_major_ld(out, "out"), _ptr(add), _row_major_ld(add, "add"),
+                                         out.shape[0], out.shape[1], _stream()))
+
+
+class Propagate(torch.autograd.Function):
+    """all_E = propagate(E0; W) with a hand-written backward (NGCF.py:120-147)."""
+
+    @staticmethod
+    def forward(ctx, owner, csrs, csrs_t, drop, seeds, n_layer, user_w, item_w, *params):
+        w1, b1 = params[:n_layer], params[n_layer:2 * n_layer]
+        w2, b2 = params[2 * n_layer:3 * n_layer], params[3 * n_layer:]
+        dev = user_w.device
+        U, I = int(user_w.shape[0]), int(item_w.shape[0])
+        N, d0 = U + I, int(user_w.shape[1])
+        widths = [d0] + [int(w.shape[0]) for w in w1]
+        all_E = torch.empty((N, sum(widths)), dtype=torch.float32, device=dev)
+        _eng.copy_rows(user_w.detach(), all_E[:U, :d0])
+        _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
+        prev = all_E[:, :d0]
+        off = d0
+        ins, les, carries = [], [], []
+        for k in range(n_layer):
+            d_out = widths[k + 1]
+            LE = _eng.spmm(csrs[k], prev, ws=owner._ws)                      # saved for the backward
+            carry = torch.empty((N, d_out), dtype=torch.float32, device=dev)
+            _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
+                             all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
+            ins.append(prev)
+            les.append(LE)
+            carries.append(carry)
+            prev = carry
+            off += d_out
+        ctx.owner, ctx.csrs_t, ctx.drop, ctx.seeds, ctx.n_layer = owner, csrs_t, drop, seeds, n_layer
+        ctx.widths, ctx.U = widths, U
+        ctx.save_for_backward(all_E, *les, *carries, *[p.detach() for p in params])
+        return all_E
+
+    @staticmethod
+    def backward(ctx, g_all):
+        n, widths, U = ctx.n_layer, ctx.widths, ctx.U
+        saved = ctx.saved_tensors
+        all_E = saved[0]
+        les, carries = saved[1:1 + n], saved[1 + n:1 + 2 * n]
+        params = saved[1 + 2 * n:]
+        w1, w2 = params[:n], params[2 * n:3 * n]
+        g_all = g_all.contiguous()
+        ws = ctx.owner._ws
+        gw1, gb1, gw2, gb2 = [None] * n, [None] * n, [None] * n, [None] * n
+        dC = None
+        offs = [sum(widths[:k + 1]) for k in range(n)]
+        for k in reversed(range(n)):
+            d_in, d_out = widths[k], widths[k + 1]
+            E_k = all_E[:, :widths[0]] if k == 0 else carries[k - 1]
+            LE_k, C_k = les[k], carries[k]
+            dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k])
+            SP = _sp_concat(LE_k, E_k)
+            gW = dM.t().mm(SP)                                                   # library GEMM: [d_out, 2 d_in]
+            gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
+            gb = dM.sum(0)
+            gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
+            del SP
+            dSP = dM.mm(torch.cat((w1[k], w2[k]), dim=1))                        # library GEMM: [N, 2 d_in]
+            dLE, dE = _bwd_combine(dSP, LE_k, E_k)
+            del dSP, dM
+            _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws))                   # dE += L^T . dLE
+            dC = dE
+        dE0 = dC
+        _add_rows(dE0, g_all[:, :widths[0]])                                     # the all_E block of E0 itself
+        return (None, None, None, None, None, None, dE0[:U], dE0[U:], *gw1, *gb1, *gw2, *gb2)
+
+
+class GatherTriple(torch.autograd.Function):
+    """(u, pos, neg) row gathers of NGCF.py:151-155; backward scatters into one dense gradient of all_E."""
+
+    @staticmethod
+    def forward(ctx, all_E, n_user, status, u_idx, p_idx, n_idx):
+        U = int(n_user)
+        n_item = int(all_E.shape[0]) - U
+        u = _eng.gather_rows(all_E, u_idx, status, 0, U)
+        p = _eng.gather_rows(all_E, p_idx, status, U, n_item)
+        n = _eng.gather_rows(all_E, n_idx, status, U, n_item) if n_idx is not None else None
+        ctx.shape, ctx.U, ctx.has_n = tuple(all_E.shape), U, n_idx is not None
+        ctx.save_for_backward(u_idx, p_idx, *([n_idx] if n_idx is not None else []))
+        return (u, p, n) if n is not None else (u, p)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        idx = ctx.saved_tensors
+        N, D = ctx.shape
+        G = torch.zeros((N, D), dtype=torch.float32, device=grads[0].device)
+        offs = (0, ctx.U, ctx.U)
+        lims = (ctx.U, N - ctx.U, N - ctx.U)
+        with torch.cuda.device(G.device):
+            for g, ix, off, lim in zip(grads, idx, offs, lims):
+                if g is None:
+                    continue
+                g = g.contiguous()
+                _lib.check(lib.ngcf_scatter_add_rows_f32(_ptr(G), D, D, _ptr(ix), ix.numel(), off, lim, _ptr(g), D, _stream()))
+        return (G, None, None, None, None, None)
+
+
+class BPRLoss(torch.autograd.Function):
+    """Fused BPR (bprloss.py:15-22) with its gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, u, p, n, weight_decay, batch_size, ws):
+        ctx.wd, ctx.bs = float(weight_decay), float(batch_size)
+        ctx.save_for_backward(u, p, n)
+        return _eng.bpr_loss(u, p, n, weight_decay, batch_size, ws)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        u, p, n = (t.contiguous() for t in ctx.saved_tensors)
+        du, dp, dn = torch.empty_like(u), torch.empty_like(p), torch.empty_like(n)
+        g = g.to(torch.float32).contiguous()
+        with torch.cuda.device(u.device):
+            _lib.check(lib.ngcf_bpr_backward_f32(_ptr(u), u.shape[0], _ptr(p), p.shape[0], _ptr(n), n.shape[0], u.shape[1],
+                                                 ctx.wd, ctx.bs, _ptr(g), _ptr(du), _ptr(dp), _ptr(dn), _stream()))
+        return du, dp, dn, None, None, None
+
+
+def propagate_with_grad(owner, csrs, csrs_t_fn, user_w, item_w, w1, b1, w2, b2, drop, seeds) -> torch.Tensor:
+    """Inference path unless a gradient can flow; then the autograd Function (needs the CSRs of L^T)."""
+    params = list(w1) + list(b1) + list(w2) + list(b2)
+    need = torch.is_grad_enabled() and any(t.requires_grad for t in [user_w, item_w] + params)
+    if not need:
+        with torch.no_grad():
+            return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds)
+    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), list(seeds), len(w1), user_w, item_w, *params)

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as _eng
+from .autograd import BPRLoss
 
 
 class BPR(nn.Module):
@@ -21,5 +22,7 @@ class BPR(nn.Module):
         self._ws = _eng.Workspace()
 
     def forward(self, u_idx, pos_idx, neg_idx):
+        if torch.is_grad_enabled() and (u_idx.requires_grad or pos_idx.requires_grad or neg_idx.requires_grad):
+            return BPRLoss.apply(u_idx, pos_idx, neg_idx, self.weight_decay, self.batch_size, self._ws)
         return _eng.bpr_loss(u_idx.detach(), pos_idx.detach(), neg_idx.detach(), self.weight_decay,
                              self.batch_size, self._ws)

@@ -1,0 +1,138 @@
+"""GPU tests of the backward pass (`loss.backward()`, experiment.py:57): gradients of every parameter from the
+HIP path vs torch autograd through the CPU oracle (op-for-op restatement of the reference), rtol 2e-3."""
+import numpy as np
+import pytest
+import torch
+
+import ngcf_oracle as orc
+from conftest import load_golden
+from golden_util import batch_of, ctor_args, lap_list_of, layer_params, sd_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _pkg():
+    import seoul_tourism_recommendation_ngcf_amd as pkg
+    return pkg
+
+
+def _oracle_grads(g, sd, b, node_flag, rng_state=None, wd=0.025):
+    n_layer = len(g["layers"])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(("w1_list", "w2_list", "item_emb"))}
+    uw = torch.from_numpy(g["out_user_weight_after"]).clone().requires_grad_(True)     # state after the injection
+    w1 = [leaves[f"w1_list.{k}.weight"] for k in range(n_layer)]
+    b1 = [leaves[f"w1_list.{k}.bias"] for k in range(n_layer)]
+    w2 = [leaves[f"w2_list.{k}.weight"] for k in range(n_layer)]
+    b2 = [leaves[f"w2_list.{k}.bias"] for k in range(n_layer)]
+    L = lap_list_of(g)[int(g["year_idx"])]
+    if rng_state is not None:
+        torch.set_rng_state(rng_state)
+    all_E = orc.propagate_torch(L, uw, leaves["item_embedding.weight"], w1, b1, w2, b2, mess_dropout=None,
+                                training=False, node_dropout=float(g["meta"][5]), node_flag=node_flag)
+    u, p, n = orc.gather_torch(all_E, int(g["meta"][0]), b["u_id"], b["pos_item"], b["neg_item"])
+    loss = orc.bpr_torch(u, p, n, wd, len(b["u_id"]))
+    loss.backward()
+    grads = {k: v.grad for k, v in leaves.items()}
+    grads["user_embedding.weight"] = uw.grad
+    return float(loss), grads
+
+
+@pytest.mark.parametrize("name,node_flag", [("fwd_sigA_small", False), ("fwd_sigB_y19", False), ("fwd_130_128", False),
+                                            ("fwd_train_dropout", True)])
+def test_parameter_gradients_match_oracle_autograd(name, node_flag, dev):
+    pkg = _pkg()
+    g = load_golden(name)
+    sd, b = sd_of(g), batch_of(g)
+    model = pkg.NGCF(**ctor_args(g, lap_list_of(g, dev), dev)).to(dev)
+    model.load_state_dict(sd)
+    model.eval()                                   # message dropout off; node dropout follows node_flag
+    batch = {k: v.to(dev) for k, v in b.items()}
+    crit = pkg.BPR(0.025, len(b["u_id"]))
+    rng_state = torch.from_numpy(g["rng_state"]) if node_flag else None
+    if node_flag:
+        torch.set_rng_state(rng_state)
+    u, p, n = model(node_flag=node_flag, **batch)
+    assert u.requires_grad and p.requires_grad
+    loss = crit(u, p, n)
+    loss.backward()
+    want_loss, want = _oracle_grads(g, sd, b, node_flag, rng_state)
+    assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss)
+    named = dict(model.named_parameters())
+    for k, wg in want.items():
+        got = named[k].grad
+        assert got is not None, k
+        scale = float(wg.abs().max())
+        np.testing.assert_allclose(got.cpu().numpy(), wg.numpy(), atol=2e-3 * scale + 1e-9, rtol=2e-3, err_msg=k)
+    for k in ("age_emb.weight", "sex_emb.weight", "month_emb.weight", "day_emb.weight", "dow_emb.weight"):
+        assert named[k].grad is None               # the injection goes through .data (NGCF.py:114): no gradient
+
+
+def test_training_step_with_adam_runs_and_lowers_the_loss(dev):
+    """The experiment.py:45-59 pattern: forward(node_flag=True) -> BPR -> backward -> Adam.step, in train mode."""
+    pkg = _pkg()
+    g = load_golden("fwd_sigB_y19")
+    sd, b = sd_of(g), batch_of(g)
+    model = pkg.NGCF(**ctor_args(g, lap_list_of(g, dev), dev)).to(dev)
+    model.load_state_dict(sd)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    crit = pkg.BPR(0.025, len(b["u_id"])).to(dev)
+    batch = {k: v.to(dev) for k, v in b.items()}
+    torch.manual_seed(0)
+    losses = []
+    total = 0
+    for _ in range(6):
+        u, p, n = model(node_flag=True, **batch)
+        opt.zero_grad()
+        loss = crit(u, p, n)
+        loss.backward()
+        opt.step()
+        total += loss
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_dropout_backward_matches_autograd_on_the_realised_mask(dev):
+    """Message dropout: the backward must use exactly the forward's keep mask (recomputed from the seed)."""
+    pkg = _pkg()
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    eng = pkg.engine
+    n, d, p = 300, 96, 0.3
+    gen = torch.Generator().manual_seed(2)
+    LE, E = (torch.randn((n, d), generator=gen) * 0.4 for _ in range(2))
+    W1, W2 = (torch.randn((d, d), generator=gen) * 0.1 for _ in range(2))
+    b1, b2 = (torch.randn((d,), generator=gen) * 0.1 for _ in range(2))
+    dN, dC = (torch.randn((n, d), generator=gen) for _ in range(2))
+    carry = torch.empty((n, d), device=dev)
+    nb = torch.empty((n, d), device=dev)
+    eng.layer_dense(LE.to(dev), E.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), carry, nb, eng.Workspace(),
+                    drop_p=p, drop_seed=99)
+    dM = ag._bwd_pre(dN.to(dev), dC.to(dev), carry, 0.2, p, 99).cpu()
+    # reference: autograd through leaky -> (mask/(1-p)) -> normalise with the realised mask
+    M = (torch.nn.functional.linear(LE, W1, b1) + torch.nn.functional.linear(E, W1, b1)
+         + torch.nn.functional.linear(LE * E, W2, b2)).requires_grad_(True)
+    A = torch.nn.functional.leaky_relu(M, 0.2)
+    mask = (carry.cpu() != 0) | (A.detach() == 0)
+    Cc = A * mask / (1 - p)
+    Nn = torch.nn.functional.normalize(Cc, p=2, dim=1)
+    ((Nn * dN).sum() + (Cc * dC).sum()).backward()
+    np.testing.assert_allclose(dM.numpy(), M.grad.numpy(), atol=2e-5, rtol=2e-3)
+
+
+def test_bpr_backward_matches_golden_grads(dev):
+    pkg = _pkg()
+    g = load_golden("bpr")
+    for tag in ("full", "bcast", "one"):
+        u, p, n = (torch.from_numpy(g[f"{tag}_{k}"]).to(dev).requires_grad_(True) for k in "upn")
+        wd, bs = (float(x) for x in g[f"{tag}_wd_bs"])
+        loss = pkg.BPR(wd, int(bs))(u, p, n)
+        (3.0 * loss).backward()                    # non-unit upstream gradient
+        for t, k in ((u, "gu"), (p, "gp"), (n, "gn")):
+            want = 3.0 * g[f"{tag}_{k}"]
+            np.testing.assert_allclose(t.grad.cpu().numpy(), want, atol=1e-7 + 1e-5 * np.abs(want).max(), rtol=1e-4)

@@ -180,7 +180,7 @@ def _gpu_worker(rank, world, port, mode, ret):
         num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
         torch.manual_seed(7)
         model = pkg.NGCF(128, [128, 64], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 64, dev).to(dev).eval()
-        want = model.propagate(0).clone()
+        want = model.propagate(0).detach().clone()
         sh = nd.ShardedPropagation(model, coo["rows"], coo["cols"], coo["vals"], mode=mode)
         au, ai = sh.propagate()
         if mode == "bipartite":

@@ -82,7 +82,7 @@ def test_module_forward_matches_golden(name, lap_on, dev):
     torch.cuda.synchronize()
     # in-place mutation of user_embedding.weight: bit-exact
     assert np.array_equal(model.user_embedding.weight.detach().cpu().numpy(), g["out_user_weight_after"])
-    all_E = torch.cat((model.all_users_emb, model.all_items_emb), 0).cpu().numpy()
+    all_E = torch.cat((model.all_users_emb, model.all_items_emb), 0).detach().cpu().numpy()
     assert all_E.shape == g["out_all_E"].shape
     assert np.array_equal(all_E[:, :int(g["meta"][2])],
                           np.concatenate([g["out_user_weight_after"], sd["item_embedding.weight"].numpy()]))
@@ -98,11 +98,11 @@ def test_module_forward_matches_golden(name, lap_on, dev):
     # gathers: bit-exact copies of the engine's own rows, and within tolerance of the reference's
     assert torch.equal(u, model.all_users_emb[batch["u_id"]])
     assert torch.equal(p, model.all_items_emb[batch["pos_item"]])
-    np.testing.assert_allclose(u.cpu().numpy(), g["out_u"], atol=ATOL, rtol=RTOL)
-    np.testing.assert_allclose(p.cpu().numpy(), g["out_p"], atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), g["out_u"], atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(p.detach().cpu().numpy(), g["out_p"], atol=ATOL, rtol=RTOL)
     if g["out_n"].size:
         assert torch.equal(n, model.all_items_emb[batch["neg_item"]])
-        np.testing.assert_allclose(n.cpu().numpy(), g["out_n"], atol=ATOL, rtol=RTOL)
+        np.testing.assert_allclose(n.detach().cpu().numpy(), g["out_n"], atol=ATOL, rtol=RTOL)
     else:
         assert n.numel() == 0 and n.device.type == "cpu"              # `torch.empty(0)`, NGCF.py:153
     assert u.shape == (len(b["u_id"]), all_E.shape[1])
@@ -124,7 +124,7 @@ def test_module_node_dropout_reference_mode_matches_golden_edge_sets(dev):
     batch = {k: v.to(dev) for k, v in b.items()}
     torch.set_rng_state(torch.from_numpy(g["rng_state"]))
     model(node_flag=True, **batch)
-    got = torch.cat((model.all_users_emb, model.all_items_emb), 0).cpu().numpy()
+    got = torch.cat((model.all_users_emb, model.all_items_emb), 0).detach().cpu().numpy()
     # oracle with the same CPU generator state
     user_w = torch.from_numpy(g["out_user_weight_after"])
     w1, b1, w2, b2 = layer_params(sd, 3)
@@ -153,23 +153,23 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
     for seg in (512, 64):                     # default plan, then force row segmentation of the long rows
         csr.plan(seg)
         assert csr.n_segments == sum(-(-int(k) // seg) for k in np.diff(rowptr) if k > seg)
-        got = eng.spmm(csr, Ed).cpu().numpy()
+        got = eng.spmm(csr, Ed).detach().cpu().numpy()
         np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
         assert np.all(got[[0, 1, 500]] == 0)                      # empty rows are written as zeros
     if d % 64 == 0:
         # the experimental L2-swept kernel (opt-in); rows longer than the per-owner budget are dealt to several
         # pieces -> partial sums + fix-up
         csr.set_mode(2)
-        got = eng.spmm(csr, Ed).cpu().numpy()
+        got = eng.spmm(csr, Ed).detach().cpu().numpy()
         np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
         assert np.all(got[[0, 1, 500]] == 0)
-        got2 = eng.spmm(csr, Ed).cpu().numpy()
+        got2 = eng.spmm(csr, Ed).detach().cpu().numpy()
         assert np.array_equal(got, got2)                          # deterministic: fixed summation order
         csr.set_mode(1)
     # a column-sliced (strided) operand, as the engine uses for all_E blocks
     big = torch.zeros((n_cols, d + 24), device=dev)
     big[:, 8:8 + d] = Ed
-    got = eng.spmm(csr, big[:, 8:8 + d]).cpu().numpy()
+    got = eng.spmm(csr, big[:, 8:8 + d]).detach().cpu().numpy()
     np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
 
 
@@ -195,7 +195,7 @@ def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
     rp = torch.searchsorted(coo["rows"], torch.stack([rows, rows + 1]))
     for r, (lo, hi) in zip(rows.tolist(), rp.T.tolist()):
         want = (coo["vals"][lo:hi].double()[:, None] * X[coo["cols"][lo:hi]].double()).sum(0)
-        np.testing.assert_allclose(swept[r].cpu().numpy(), want.cpu().numpy(), atol=ATOL, rtol=RTOL)
+        np.testing.assert_allclose(swept[r].detach().cpu().numpy(), want.detach().cpu().numpy(), atol=ATOL, rtol=RTOL)
 
 
 def test_spmm_unsorted_and_duplicate_coo(dev, oracle_clib):
@@ -210,7 +210,7 @@ def test_spmm_unsorted_and_duplicate_coo(dev, oracle_clib):
     want = orc.spmm_coo_f64(rows2, cols2, vals2, n, E)
     csr = eng.LaplacianCSR.from_coo(*(torch.from_numpy(a[perm]).to(dev) for a in (rows2, cols2, vals2)), n, n)
     assert csr.nnz == len(rows2)                       # duplicates kept as separate entries
-    got = eng.spmm(csr, torch.from_numpy(E).to(dev)).cpu().numpy()
+    got = eng.spmm(csr, torch.from_numpy(E).to(dev)).detach().cpu().numpy()
     np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
 
 
@@ -256,8 +256,8 @@ def test_layer_dense_matches_oracle(d_in, d_out, n_rows, dev):
     allE = torch.full((n_rows, d_out + 9), float("nan"), device=dev)
     ws = eng.Workspace()
     eng.layer_dense(LE.to(dev), E.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), carry, allE[:, 5:5 + d_out], ws)
-    np.testing.assert_allclose(carry.cpu().numpy(), want_c.numpy(), atol=ATOL, rtol=RTOL)
-    np.testing.assert_allclose(allE[:, 5:5 + d_out].cpu().numpy(), want_n.numpy(), atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(carry.detach().cpu().numpy(), want_c.numpy(), atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(allE[:, 5:5 + d_out].detach().cpu().numpy(), want_n.numpy(), atol=ATOL, rtol=RTOL)
     assert torch.isnan(allE[:, :5]).all() and torch.isnan(allE[:, 5 + d_out:]).all()    # nothing outside the block
     # last layer: carry omitted
     allE2 = torch.empty((n_rows, d_out), device=dev)
@@ -298,9 +298,9 @@ def test_message_dropout_statistics_and_determinism(dev):
     frac = float(dropped.float().mean())
     assert abs(frac - p) < 0.01
     kept = ~dropped
-    np.testing.assert_allclose(c1[kept].cpu().numpy(), (base[kept] / (1 - p)).cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(c1[kept].detach().cpu().numpy(), (base[kept] / (1 - p)).detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
     # normalised block is the normalisation of the dropped carry
-    np.testing.assert_allclose(nb.cpu().numpy(), torch.nn.functional.normalize(c3, dim=1).cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(nb.detach().cpu().numpy(), torch.nn.functional.normalize(c3, dim=1).detach().cpu().numpy(), atol=1e-6)
 
 
 # --------------------------------------------------------------------------------------------
@@ -315,12 +315,12 @@ def test_propagate_medium_graph(d0, layers, dev):
     num_dict = {"user": n_user, "item": n_item, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
     torch.manual_seed(4)
     model = pkg.NGCF(d0, list(layers), 0.3, [0.1] * len(layers), 1.0, [lap], num_dict, 1024, dev).to(dev).eval()
-    all_E = model.propagate(0).cpu()
+    all_E = model.propagate(0).detach().cpu()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     w1, b1, w2, b2 = layer_params(sd, len(layers))
     want = orc.propagate_torch(lap.cpu(), sd["user_embedding.weight"], sd["item_embedding.weight"], w1, b1, w2, b2)
     np.testing.assert_allclose(all_E.numpy(), want.numpy(), atol=ATOL, rtol=RTOL)
-    f64 = orc.propagate_f64(coo["rows"].cpu().numpy(), coo["cols"].cpu().numpy(), coo["vals"].cpu().numpy(),
+    f64 = orc.propagate_f64(coo["rows"].detach().cpu().numpy(), coo["cols"].detach().cpu().numpy(), coo["vals"].detach().cpu().numpy(),
                             want[:, :d0].numpy(), [w.numpy() for w in w1], [x.numpy() for x in b1],
                             [w.numpy() for w in w2], [x.numpy() for x in b2])
     ref_err = np.abs(want.numpy() - f64).max()
@@ -361,7 +361,7 @@ def test_spmm_linearity_and_permutation_invariance_large(dev):
     rp = torch.searchsorted(coo["rows"], torch.stack([rows, rows + 1]))
     for r, (lo, hi) in zip(rows.tolist()[-8:], rp.T.tolist()[-8:]):
         want = (coo["vals"][lo:hi].double()[:, None] * X[coo["cols"][lo:hi]].double()).sum(0)
-        np.testing.assert_allclose(LX[r].cpu().numpy(), want.cpu().numpy(), atol=ATOL, rtol=RTOL)
+        np.testing.assert_allclose(LX[r].detach().cpu().numpy(), want.detach().cpu().numpy(), atol=ATOL, rtol=RTOL)
 
 
 # --------------------------------------------------------------------------------------------
