@@ -1059,8 +1059,15 @@ static int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, 
                          void *workspace, int64_t workspace_bytes, hipStream_t stream)
 {
     if (!c || !E || !out) return fail(NGCF_ERR_ARG, "spmm: null argument");
-    if (d <= 0 || d > 512) return fail(NGCF_ERR_ARG, "spmm: width d=%d not in [1, 512]", d);
+    if (d <= 0 || d > 8192) return fail(NGCF_ERR_ARG, "spmm: width d=%d not in [1, 8192]", d);
     if (ldE < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm: leading dimension smaller than d");
+    if (d > 512) {   // wider than one wave covers: column panels of 512 (Seoul's 515-wide first layer, BASELINE configs[1])
+        for (int o = 0; o < d; o += 512) {
+            const int rc = spmm_dispatch(c, E + o, ldE, std::min(512, d - o), out + o, ldo, workspace, workspace_bytes, stream);
+            if (rc != NGCF_OK) return rc;
+        }
+        return NGCF_OK;
+    }
     const int dp = (int)align_up(d, 4);
     float *partial = nullptr;
     if (c->n_seg > 0) {
