@@ -87,11 +87,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # NGCF_BENCH_SHARE_GPU=1 is a rehearsal mode for a one-GPU box: all ranks use cuda:0 over gloo (RCCL refuses
+    # two ranks on one device); the driver's runs use one GPU per rank over "nccl" (= RCCL).
+    share = os.environ.get("NGCF_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import seoul_tourism_recommendation_ngcf_amd as pkg
     from seoul_tourism_recommendation_ngcf_amd import _lib, dist as ngcf_dist

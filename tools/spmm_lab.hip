@@ -42,3 +42,52 @@ extern "C" int lab_launch(int variant, const int64_t *ubeg, const int64_t *uend,
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
+// accumulate variant: out[dst] (+)= sum over the unit; used by the column-blocked experiment
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void lab_spmm_acc(const int64_t *__restrict__ ubeg, const int64_t *__restrict__ uend,
+                                                    int64_t n_units, int64_t unit_blocks,
+                                                    const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                                    const float *__restrict__ E, int64_t ldE, float *__restrict__ out,
+                                                    int64_t ldo, int accumulate)
+{
+    const int64_t slice = blockIdx.x / unit_blocks;
+    const int64_t unit = (blockIdx.x % unit_blocks) * 4 + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    constexpr int S = LPR * 4;
+    const int64_t b = ubeg[unit], e = uend[unit];
+    if (b == e && accumulate) return;
+    float4 acc[1];
+    acc[0] = vzero4();
+    spmm_accumulate<4, LPR, 1, U>(colidx, vals, b, e, E + slice * S, ldE, S, acc);
+    const int lane = threadIdx.x & 63;
+    if (lane < LPR) {
+        float4 *p = reinterpret_cast<float4 *>(out + unit * ldo + slice * S + lane * 4);
+        if (accumulate) {
+            const float4 t = *p;
+            acc[0] = vadd(acc[0], t);
+        }
+        *p = acc[0];
+    }
+}
+
+extern "C" int lab_launch_acc(int variant, const int64_t *ubeg, const int64_t *uend, int64_t n_units, const int32_t *colidx,
+                              const float *vals, const float *E, int64_t ldE, int d, float *out, int64_t ldo, int accumulate,
+                              void *stream_)
+{
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t ubk = (n_units + 3) / 4;
+#define GO2(LPR, U) \
+    lab_spmm_acc<LPR, U><<<dim3((unsigned)(ubk * (d / (4 * LPR)))), 256, 0, s>>>(ubeg, uend, n_units, ubk, colidx, vals, E, ldE, out, ldo, accumulate)
+    switch (variant) {
+    case 0: GO2(8, 2); break;
+    case 1: GO2(8, 4); break;
+    case 2: GO2(8, 8); break;
+    case 3: GO2(16, 2); break;
+    case 4: GO2(16, 4); break;
+    case 5: GO2(32, 2); break;
+    case 6: GO2(32, 4); break;
+    default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
