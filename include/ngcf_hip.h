@@ -192,6 +192,13 @@ int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, 
 /* out[r, 0:d] += add[r, 0:d] */
 int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream);
 
+/* ---- top-k of score rows (experiment.py:104-111, demo.py:234-235: `torch.topk(torch.mm(u, items.T), k)`) ---- */
+/* out_val/out_idx [n_rows, k]: the k largest entries of every row of `scores` [n_rows, n_cols] in descending
+ * order (equal values: lowest column first; NaN sorts above +inf like torch.topk).  1 <= k <= min(n_cols, 1024).
+ * The score matrix is a plain GEMM and is left to the caller. */
+int ngcf_topk_rows_f32(const float *scores, int64_t ld, int64_t n_rows, int64_t n_cols, int k, float *out_val,
+                       int64_t *out_idx, void *stream);
+
 /* ---- multi-GPU row partition (new design; host-only helper) --------------- */
 /*
  * Cut rows [row_begin, row_end) into `world` contiguous ranges of roughly equal stored-entry

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "ngcf_sp_concat_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     "ngcf_layer_bwd_combine_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp]),
     "ngcf_add_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
+    "ngcf_topk_rows_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp]),
     "ngcf_shard_plan": (C.c_int, [C.POINTER(_i64), _i64, _i64, C.c_int, C.POINTER(_i64)]),
 }
 

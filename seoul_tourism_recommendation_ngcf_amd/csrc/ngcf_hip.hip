@@ -1982,3 +1982,142 @@ extern "C" int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int6
     LAUNCH_CHECK();
     return NGCF_OK;
 }
+
+// =============================================================================================
+// Top-k selection per row (`torch.topk` on the score matrix, experiment.py:104-111,
+// demo.py:234-235).  One workgroup per row: a 4-pass 8-bit radix select finds the k-th largest key, one more
+// pass collects the k winners (ties at the threshold: lowest column first), a bitonic sort in LDS orders them
+// descending (equal values: lowest column first).  The score matrix itself is a plain GEMM (u . items^T).
+// =============================================================================================
+#define NGCF_TOPK_MAX 1024
+
+__device__ inline uint32_t float_key(float x)      // monotone map float -> uint32 (larger float = larger key)
+{
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_cols, int k,
+                                                        int kp2, float *__restrict__ out_val, int64_t *__restrict__ out_idx)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_need, sh_cnt_gt, sh_cnt_eq;
+    __shared__ uint32_t skey[NGCF_TOPK_MAX];
+    __shared__ int32_t sidx[NGCF_TOPK_MAX];
+    const float *row = scores + (int64_t)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    // ---- radix select: after the 4 passes `prefix` is the key of the k-th largest element
+    uint32_t prefix = 0, need = (uint32_t)k;      // `need` = how many of the current prefix class are still wanted
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t mask_hi = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int64_t j = tid; j < n_cols; j += 256) {
+            const uint32_t key = float_key(row[j]);
+            if ((key & mask_hi) == (prefix & mask_hi)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            int dsel = 0;
+            for (int dgt = 255; dgt >= 0; --dgt) {
+                if (acc + hist[dgt] >= need) {
+                    dsel = dgt;
+                    break;
+                }
+                acc += hist[dgt];
+            }
+            sh_prefix = prefix | ((uint32_t)dsel << shift);
+            sh_need = need - acc;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        __syncthreads();
+    }
+    // ---- collect: all keys above the threshold, then `need` keys equal to it in column order
+    if (tid == 0) {
+        sh_cnt_gt = 0;
+        sh_cnt_eq = 0;
+    }
+    for (int j = tid; j < kp2; j += 256) {
+        skey[j] = 0u;                     // padding sorts last
+        sidx[j] = 0x7fffffff;
+    }
+    __syncthreads();
+    const uint32_t n_gt = (uint32_t)k - need;
+    for (int64_t j0 = 0; j0 < n_cols; j0 += 256) {         // block-ordered so that ties keep the lowest columns
+        const int64_t j = j0 + tid;
+        uint32_t key = 0;
+        bool gt = false, eq = false;
+        if (j < n_cols) {
+            key = float_key(row[j]);
+            gt = key > prefix;
+            eq = key == prefix;
+        }
+        if (gt) {
+            const uint32_t pos = atomicAdd(&sh_cnt_gt, 1u);
+            skey[pos] = key;
+            sidx[pos] = (int32_t)j;
+        }
+        // equal keys: rank inside this 256-column block by a wave/LDS-free trick - serialise through LDS counter in order
+        __syncthreads();
+        if (eq) hist[tid] = 1; else hist[tid] = 0;
+        __syncthreads();
+        if (eq) {
+            uint32_t before = 0;
+            for (int t = 0; t < tid; ++t) before += hist[t];
+            const uint32_t pos = sh_cnt_eq + before;
+            if (pos < need) {
+                skey[n_gt + pos] = key;
+                sidx[n_gt + pos] = (int32_t)j;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int t = 0; t < 256; ++t) tot += hist[t];
+            sh_cnt_eq += tot;
+        }
+        __syncthreads();
+    }
+    // ---- bitonic sort, descending by (key, then ascending column)
+    for (int size = 2; size <= kp2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < kp2; i += 256) {
+                const int p = i ^ stride;
+                if (p > i) {
+                    const bool desc = (i & size) == 0;
+                    const uint32_t ka = skey[i], kb = skey[p];
+                    const int32_t ia = sidx[i], ib = sidx[p];
+                    const bool a_first = ka > kb || (ka == kb && ia < ib);     // a belongs before b in the final order
+                    if (a_first != desc) {
+                        skey[i] = kb; skey[p] = ka;
+                        sidx[i] = ib; sidx[p] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += 256) {
+        out_idx[(int64_t)blockIdx.x * k + j] = sidx[j];
+        out_val[(int64_t)blockIdx.x * k + j] = row[sidx[j]];
+    }
+}
+
+extern "C" int ngcf_topk_rows_f32(const float *scores, int64_t ld, int64_t n_rows, int64_t n_cols, int k, float *out_val,
+                                  int64_t *out_idx, void *stream_)
+{
+    if (n_rows == 0) return NGCF_OK;
+    if (!scores || !out_val || !out_idx || ld < n_cols) return fail(NGCF_ERR_ARG, "topk_rows: bad argument");
+    if (k < 1 || k > n_cols) return fail(NGCF_ERR_ARG, "selected index k out of range (k=%d, row length %lld)", k, (long long)n_cols);
+    if (k > NGCF_TOPK_MAX) return fail(NGCF_ERR_ARG, "topk_rows: k=%d > %d is not supported", k, NGCF_TOPK_MAX);
+    if (n_cols >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "topk_rows: row too long");
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    topk_rows_kernel<<<dim3((unsigned)n_rows), 256, 0, (hipStream_t)stream_>>>(scores, ld, n_cols, k, kp2, out_val, out_idx);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}

@@ -288,6 +288,28 @@ def bpr_loss(u: torch.Tensor, p: torch.Tensor, n: torch.Tensor, weight_decay: fl
     return loss
 
 
+def topk_rows(scores: torch.Tensor, k: int):
+    """`torch.topk(scores, k)` for a 2-D fp32 score matrix (values, int64 indices), through ngcf_topk_rows_f32."""
+    lib = _lib.load()
+    _f32c(scores, "scores")
+    if scores.dim() != 2:
+        raise RuntimeError("topk_rows: expected a 2-D score matrix")
+    n_rows, n_cols = int(scores.shape[0]), int(scores.shape[1])
+    scores = scores if scores.stride(1) == 1 else scores.contiguous()
+    vals = torch.empty((n_rows, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((n_rows, k), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(lib.ngcf_topk_rows_f32(_ptr(scores), _row_major_ld(scores, "scores"), n_rows, n_cols, int(k), _ptr(vals),
+                                          _ptr(idx), _stream()))
+    return vals, idx
+
+
+def recommend_topk(u_emb: torch.Tensor, item_emb: torch.Tensor, k: int):
+    """Scores of every item for every user row and their top-k (experiment.py:93,104-111; demo.py:234-235):
+    the score matrix is one library GEMM, the selection the HIP radix-select kernel."""
+    return topk_rows(torch.mm(u_emb, item_emb.t()), k)
+
+
 def shard_plan(rowptr_host: torch.Tensor, row_begin: int, row_end: int, world: int):
     """nnz-balanced contiguous cut of rows [row_begin,row_end) into `world` ranges (host helper)."""
     lib = _lib.load()
