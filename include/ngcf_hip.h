@@ -100,6 +100,19 @@ int ngcf_spmm_csr_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d,
                       int64_t ldLE, void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
+ * LE = drop(L).E with node dropout on the device (NGCF.py:93-100,124-126 semantics: every stored entry is kept
+ * with probability 1-p, values are NOT rescaled, and the thinning is cumulative over layers): entry e survives
+ * iff hash(seeds[j], e) passes for every j < n_seeds (layer k passes its own and all earlier layers' seeds,
+ * n_seeds <= 4, host array).  No CSR is rebuilt; dropped entries are compacted away inside each wave.
+ * `eid` (device int64[nnz], may be NULL) gives, for a transposed CSR, the entry number in L of each stored entry,
+ * so that L^T is thinned consistently in the backward pass.  The mask is a counter-based hash, not torch's
+ * generator: same distribution as the reference, different stream.
+ */
+int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
+                              float drop_p, const uint64_t *seeds, int n_seeds, const int64_t *eid,
+                              void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
  * One whole propagation layer (NGCF.py:130-146) for the rows of `csr`:
  *   LE    = L.E_gather                                              NGCF.py:130
  *   M     = (LE+E_self).W1^T + (LE*E_self).W2^T + (2*b1 + b2)       NGCF.py:131-138 (b1 twice)

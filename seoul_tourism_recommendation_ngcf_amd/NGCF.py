@@ -108,10 +108,25 @@ class NGCF(nn.Module):
             N = self.n_user + self.n_item
             if tuple(L.shape) != (N, N):
                 raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(L.shape)} and {N}x{self.emb_size})")
-            csr = _eng.LaplacianCSR.from_sparse_coo(L, dev)
-            self._csr_cache = {k: v for k, v in self._csr_cache.items() if k[0] != year_idx}
+            rows, cols, vals = self._sorted_coo(L, dev)
+            csr = _eng.LaplacianCSR.from_coo(rows, cols, vals, N, N)
+            self._csr_cache = {k: v for k, v in self._csr_cache.items() if year_idx not in k[:2]}
             self._csr_cache[key] = csr
         return csr
+
+    @staticmethod
+    def _sorted_coo(L: torch.Tensor, dev):
+        """COO triplets of a `lap_list` entry on the device, row-sorted (stable) so that the CSR keeps their order:
+        the position of an entry in this order is its entry number (used by the device-side node dropout)."""
+        if not L.is_sparse:
+            raise RuntimeError("lap_list entries must be torch sparse COO tensors (matrix.py:79-83)")
+        idx = L._indices().to(dev)
+        val = L._values().to(device=dev, dtype=torch.float32)
+        rows, cols = idx[0], idx[1]
+        if rows.numel() > 1 and bool((rows[1:] < rows[:-1]).any()):
+            order = torch.sort(rows, stable=True).indices
+            rows, cols, val = rows[order], cols[order], val[order]
+        return rows, cols, val
 
     def laplacian_csr_t(self, year_idx: int) -> "_eng.LaplacianCSR":
         """CSR of `lap_list[year_idx]` transposed (for `L^T . dLE` in the backward), built on first use."""
@@ -120,14 +135,18 @@ class NGCF(nn.Module):
         key = ("T", year_idx, id(L), str(dev))
         csr = self._csr_cache.get(key)
         if csr is None:
-            csr = self._transposed_csr(L._indices().to(dev), L._values().to(device=dev, dtype=torch.float32))
+            rows, cols, vals = self._sorted_coo(L, dev)
+            csr = self._transposed_csr(torch.stack([rows, cols]), vals)
             self._csr_cache[key] = csr
         return csr
 
     def _transposed_csr(self, idx: torch.Tensor, val: torch.Tensor) -> "_eng.LaplacianCSR":
+        """CSR of the transpose; `.eid[j]` is the entry number in the untransposed matrix of its j-th entry."""
         N = self.n_user + self.n_item
         order = torch.sort(idx[1], stable=True).indices          # by column = row of L^T, original order kept inside
-        return _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N)
+        csr = _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N)
+        csr.eid = order.contiguous()
+        return csr
 
     def _layer_params(self):
         return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],
@@ -161,11 +180,19 @@ class NGCF(nn.Module):
     def propagate(self, year_idx: int = 0, node_flag: bool = False) -> torch.Tensor:
         """all_E = [E0 | norm(E1) | ... | norm(En)]  for the current parameters; sets all_users_emb/all_items_emb."""
         self._dev()
-        if node_flag:
+        edge_drops = None
+        if node_flag and self.node_dropout_mode == "reference":
             csrs, csrs_t_fn = self._dropped_csr_list(year_idx)
         else:
             csrs = [self.laplacian_csr(year_idx)] * self.n_layer
             csrs_t_fn = lambda: [self.laplacian_csr_t(year_idx)] * self.n_layer   # noqa: E731
+            if node_flag:
+                # "device" mode: same semantics (cumulative, unscaled), mask = counter-based hash of the entry number
+                # evaluated inside the SpMM kernel; one 64-bit seed per layer from torch's CPU generator
+                if self.node_dropout_mode != "device":
+                    raise ValueError("node_dropout_mode must be 'reference' or 'device'")
+                ns = [int(x) for x in torch.randint(0, 2 ** 62, (self.n_layer,), dtype=torch.int64)]
+                edge_drops = [(ns[:k + 1], float(self.node_dropout)) for k in range(self.n_layer)]
         drop = [0.0] * self.n_layer
         if self.training and self.mess_dropout is not None:            # nn.Dropout follows train()/eval(), NGCF.py:142
             drop = [float(p) for p in self.mess_dropout[:self.n_layer]]
@@ -174,7 +201,7 @@ class NGCF(nn.Module):
             seeds = [int(s) for s in torch.randint(0, 2 ** 62, (self.n_layer,), dtype=torch.int64)]
         w1, b1, w2, b2 = self._layer_params()
         all_E = propagate_with_grad(self, csrs, csrs_t_fn, self.user_embedding.weight, self.item_embedding.weight,
-                                    w1, b1, w2, b2, drop, seeds)
+                                    w1, b1, w2, b2, drop, seeds, edge_drops)
         self._all_E = all_E
         self.all_users_emb = all_E[:self.n_user, :]                    # NGCF.py:148-149
         self.all_items_emb = all_E[self.n_user:, :]

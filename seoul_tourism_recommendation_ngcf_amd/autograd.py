@@ -19,7 +19,7 @@ from .engine import _ptr, _row_major_ld, _stream
 
 
 def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.Tensor, item_w: torch.Tensor,
-                      w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int]):
+                      w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int], edge_drops=None):
     """all_E [N, D] = [E0 | norm(E1) | ... | norm(En)] (NGCF.py:120-147), inference path.
 
     E0 is written once into its column block of all_E (this is both the `cat` of NGCF.py:120 and
@@ -47,8 +47,13 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
                 buf = torch.empty((N, d_out), dtype=torch.float32, device=dev)
                 owner._carry[k % 2] = buf
             carry = buf
-        _eng.layer_fused(csrs[k], prev, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(),
-                         carry, all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
+        if edge_drops is None:
+            _eng.layer_fused(csrs[k], prev, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(),
+                             carry, all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
+        else:   # device-side node dropout: thinned SpMM, then the dense half
+            LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=(edge_drops[k][0], edge_drops[k][1], None))
+            _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
+                             all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
         prev = carry
         off += d_out
     return all_E
@@ -101,7 +106,7 @@ class Propagate(torch.autograd.Function):
     """all_E = propagate(E0; W) with a hand-written backward (NGCF.py:120-147)."""
 
     @staticmethod
-    def forward(ctx, owner, csrs, csrs_t, drop, seeds, n_layer, user_w, item_w, *params):
+    def forward(ctx, owner, csrs, csrs_t, drop, seeds, edge_drops, n_layer, user_w, item_w, *params):
         w1, b1 = params[:n_layer], params[n_layer:2 * n_layer]
         w2, b2 = params[2 * n_layer:3 * n_layer], params[3 * n_layer:]
         dev = user_w.device
@@ -116,7 +121,8 @@ class Propagate(torch.autograd.Function):
         ins, les, carries = [], [], []
         for k in range(n_layer):
             d_out = widths[k + 1]
-            LE = _eng.spmm(csrs[k], prev, ws=owner._ws)                      # saved for the backward
+            ed = None if edge_drops is None else (edge_drops[k][0], edge_drops[k][1], None)
+            LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=ed)        # saved for the backward
             carry = torch.empty((N, d_out), dtype=torch.float32, device=dev)
             _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
                              all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
@@ -126,6 +132,7 @@ class Propagate(torch.autograd.Function):
             prev = carry
             off += d_out
         ctx.owner, ctx.csrs_t, ctx.drop, ctx.seeds, ctx.n_layer = owner, csrs_t, drop, seeds, n_layer
+        ctx.edge_drops = edge_drops
         ctx.widths, ctx.U = widths, U
         ctx.save_for_backward(all_E, *les, *carries, *[p.detach() for p in params])
         return all_E
@@ -157,11 +164,12 @@ class Propagate(torch.autograd.Function):
             dSP = dM.mm(torch.cat((w1[k], w2[k]), dim=1))                        # library GEMM: [N, 2 d_in]
             dLE, dE = _bwd_combine(dSP, LE_k, E_k)
             del dSP, dM
-            _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws))                   # dE += L^T . dLE
+            ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], ctx.csrs_t[k].eid)
+            _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed))     # dE += (thinned L)^T . dLE
             dC = dE
         dE0 = dC
         _add_rows(dE0, g_all[:, :widths[0]])                                     # the all_E block of E0 itself
-        return (None, None, None, None, None, None, dE0[:U], dE0[U:], *gw1, *gb1, *gw2, *gb2)
+        return (None, None, None, None, None, None, None, dE0[:U], dE0[U:], *gw1, *gb1, *gw2, *gb2)
 
 
 class GatherTriple(torch.autograd.Function):
@@ -216,11 +224,11 @@ class BPRLoss(torch.autograd.Function):
         return du, dp, dn, None, None, None
 
 
-def propagate_with_grad(owner, csrs, csrs_t_fn, user_w, item_w, w1, b1, w2, b2, drop, seeds) -> torch.Tensor:
+def propagate_with_grad(owner, csrs, csrs_t_fn, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops=None) -> torch.Tensor:
     """Inference path unless a gradient can flow; then the autograd Function (needs the CSRs of L^T)."""
     params = list(w1) + list(b1) + list(w2) + list(b2)
     need = torch.is_grad_enabled() and any(t.requires_grad for t in [user_w, item_w] + params)
     if not need:
         with torch.no_grad():
-            return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds)
-    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), list(seeds), len(w1), user_w, item_w, *params)
+            return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops)
+    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), list(seeds), edge_drops, len(w1), user_w, item_w, *params)

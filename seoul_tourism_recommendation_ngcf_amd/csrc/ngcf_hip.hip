@@ -471,10 +471,31 @@ __device__ inline float vshfl_xor(float a, int m) { return __shfl_xor(a, m); }
 __device__ inline float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ inline float vadd(float a, float b) { return a + b; }
 
+// counter-based hash: the keep masks of node and message dropout are pure functions of (seed, index)
+__device__ inline uint32_t mix32(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+
+// Device-side node dropout (NGCF.py:93-100 semantics: keep each stored entry w.p. 1-p, values NOT rescaled,
+// cumulative over layers): entry e survives layer k iff mix32(seed_j ^ e*K) >= thr for every j <= k.
+// `eid` maps the entries of a transposed CSR back to the entry numbers of L (NULL: the entry position itself).
+struct EdgeDrop {
+    int n;                  // number of seeds (0 = no dropout)
+    uint32_t thr;           // p * 2^32
+    uint64_t seed[4];
+    const int64_t *eid;
+};
+
 template <int VEC, int LPR, int CH, int U>
 __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
                                        int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
-                                       int d, typename VecT<VEC>::type (&acc)[CH])
+                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr})
 {
     using V = typename VecT<VEC>::type;
     constexpr int G = 64 / LPR;
@@ -490,12 +511,26 @@ __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const
         coff[ch] = o < d ? o : 0;
     }
     for (int64_t base = begin; base < end; base += 64) {
-        const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+        int cnt = (int)((end - base) < 64 ? (end - base) : 64);
         int c = 0;       // column 0 is always a valid row of E: padding slots read it, masked below
         float v = 0.f;
         if (lane < cnt) {
             c = colidx[base + lane];
             v = vals[base + lane];
+        }
+        if (dr.n > 0) {
+            // drop entries, then compact the survivors to the low lanes (dropped ones go to the top, unused)
+            bool keep = lane < cnt;
+            if (keep) {
+                const uint64_t e = (uint64_t)(dr.eid ? dr.eid[base + lane] : base + lane) * 0x9E3779B97F4A7C15ULL;
+                for (int q = 0; q < dr.n; ++q) keep = keep && mix32(dr.seed[q] ^ e) >= dr.thr;
+            }
+            const unsigned long long m = __ballot(keep);
+            const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+            const int dst = keep ? __popcll(m & lt) : 63 - __popcll(~m & lt);
+            c = __builtin_amdgcn_ds_permute(dst << 2, c);
+            v = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v)));
+            cnt = __popcll(m);
         }
         int j = 0;
         for (; j + G * U <= cnt; j += G * U) {          // full batches: every slot is a real entry
@@ -567,7 +602,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
                                                    int64_t seg_blocks, int seg_len,
                                                    const float *__restrict__ E, int64_t ldE, int d,
                                                    float *__restrict__ out, int64_t ldo,
-                                                   float *__restrict__ partial, int dp)
+                                                   float *__restrict__ partial, int dp, EdgeDrop dr)
 {
     using V = typename VecT<VEC>::type;
     const int wave = threadIdx.x >> 6;
@@ -591,7 +626,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
     V acc[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) acc[ch] = vzero<VEC>();
-    spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc);
+    spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc, dr);
     spmm_store<VEC, LPR, CH>(acc, dst, d);
 }
 
@@ -603,7 +638,7 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
                                                           const float *__restrict__ vals, int64_t row_begin,
                                                           int64_t row_end, int64_t row_blocks, int seg_len,
                                                           const float *__restrict__ E, int64_t ldE,
-                                                          float *__restrict__ out, int64_t ldo)
+                                                          float *__restrict__ out, int64_t ldo, EdgeDrop dr)
 {
     const int64_t slice = blockIdx.x / row_blocks;
     const int64_t row = row_begin + ((int64_t)blockIdx.x % row_blocks) * 4 + (threadIdx.x >> 6);
@@ -612,7 +647,7 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
     if (end - begin > seg_len) return;   // cut row: produced from its segments
     float4 acc[1];
     acc[0] = vzero4();
-    spmm_accumulate<4, 8, 1, U>(colidx, vals, begin, end, E + slice * 32, ldE, 32, acc);
+    spmm_accumulate<4, 8, 1, U>(colidx, vals, begin, end, E + slice * 32, ldE, 32, acc, dr);
     spmm_store<4, 8, 1>(acc, out + row * ldo + slice * 32, 32);
 }
 
@@ -1007,6 +1042,7 @@ struct SpmmArgs {
     float *partial;
     int dp;
     hipStream_t stream;
+    EdgeDrop dr;
 };
 
 template <int VEC, int LPR, int CH, int U>
@@ -1027,7 +1063,7 @@ int launch_spmm(const SpmmArgs &a)
             if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
             spmm_sliced_kernel<8><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(c->rowptr, c->colidx, c->vals, c->groups[g].begin,
                                                                                c->groups[g].end, rb, c->seg_len, a.E, a.ldE,
-                                                                               a.out, a.ldo);
+                                                                               a.out, a.ldo, a.dr);
             LAUNCH_CHECK();
             continue;
         }
@@ -1039,7 +1075,7 @@ int launch_spmm(const SpmmArgs &a)
         if (blocks > 0) {
             spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
                 c->rowptr, c->colidx, c->vals, rbeg, rend, c->seg_row, c->seg_begin, seg_done ? 0 : c->n_seg, sb, c->seg_len,
-                a.E, a.ldE, a.d, a.out, a.ldo, a.partial, a.dp);
+                a.E, a.ldE, a.d, a.out, a.ldo, a.partial, a.dp, a.dr);
             LAUNCH_CHECK();
         }
         seg_done = true;
@@ -1056,14 +1092,15 @@ int launch_spmm(const SpmmArgs &a)
 }  // namespace
 
 static int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo,
-                         void *workspace, int64_t workspace_bytes, hipStream_t stream)
+                         void *workspace, int64_t workspace_bytes, hipStream_t stream,
+                         const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr})
 {
     if (!c || !E || !out) return fail(NGCF_ERR_ARG, "spmm: null argument");
     if (d <= 0 || d > 8192) return fail(NGCF_ERR_ARG, "spmm: width d=%d not in [1, 8192]", d);
     if (ldE < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm: leading dimension smaller than d");
     if (d > 512) {   // wider than one wave covers: column panels of 512 (Seoul's 515-wide first layer, BASELINE configs[1])
         for (int o = 0; o < d; o += 512) {
-            const int rc = spmm_dispatch(c, E + o, ldE, std::min(512, d - o), out + o, ldo, workspace, workspace_bytes, stream);
+            const int rc = spmm_dispatch(c, E + o, ldE, std::min(512, d - o), out + o, ldo, workspace, workspace_bytes, stream, dr);
             if (rc != NGCF_OK) return rc;
         }
         return NGCF_OK;
@@ -1076,10 +1113,10 @@ static int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, 
             return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
         partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
     }
-    SpmmArgs a{c, E, ldE, d, out, ldo, partial, dp, stream};
+    SpmmArgs a{c, E, ldE, d, out, ldo, partial, dp, stream, dr};
     const bool vec = (d % 4 == 0) && (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
     const ngcf_csr::Swept &w = c->swept;
-    if (vec && d % 64 == 0 && w.n_owners > 0 && c->mode == 2) {
+    if (vec && d % 64 == 0 && w.n_owners > 0 && c->mode == 2 && dr.n == 0) {
         if (w.n_partial > 0 && !partial) {
             const int64_t need = ngcf_spmm_workspace_bytes(c, d);
             if (!workspace || workspace_bytes < need)
@@ -1116,6 +1153,17 @@ extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ld
                                  void *workspace, int64_t workspace_bytes, void *stream)
 {
     return spmm_dispatch(c, E, ldE, d, LE, ldLE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
+                                         float drop_p, const uint64_t *seeds, int n_seeds, const int64_t *eid,
+                                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_dropout: 0..4 seeds expected");
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "spmm_dropout: drop_p=%f not in [0,1)", drop_p);
+    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, eid};
+    for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
+    return spmm_dispatch(c, E, ldE, d, LE, ldLE, workspace, workspace_bytes, (hipStream_t)stream, dr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1155,17 +1203,6 @@ __global__ void pack_weights_kernel(const float *__restrict__ W1, const float *_
     }
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < DOP; j += gridDim.x * blockDim.x)
         bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
-}
-
-// counter-based hash for the message dropout (keep mask is a pure function of seed,row,col)
-__device__ inline uint32_t mix32(uint64_t x)
-{
-    x ^= x >> 33;
-    x *= 0xff51afd7ed558ccdULL;
-    x ^= x >> 33;
-    x *= 0xc4ceb9fe1a85ec53ULL;
-    x ^= x >> 33;
-    return (uint32_t)x;
 }
 
 template <int RW, int CW, int NT, bool ALIGNED>

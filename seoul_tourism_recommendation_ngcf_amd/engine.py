@@ -149,8 +149,13 @@ class Workspace:
         return self.buf
 
 
-def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None, ws: Optional[Workspace] = None):
-    """LE = L.E (NGCF.py:130) through ngcf_spmm_csr_f32."""
+def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None, ws: Optional[Workspace] = None,
+         edge_drop=None):
+    """LE = L.E (NGCF.py:130) through ngcf_spmm_csr_f32.
+
+    `edge_drop = (seeds, p, eid)` applies device-side node dropout (ngcf_spmm_csr_dropout_f32): `seeds` the
+    cumulative list of 64-bit layer seeds, `p` the drop probability, `eid` None or the int64 entry-number map of a
+    transposed CSR."""
     lib = _lib.load()
     _f32c(E, "E")
     d = int(E.shape[1])
@@ -162,8 +167,15 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
     nb = csr.spmm_workspace_bytes(d)
     w = ws.get(nb, E.device)
     with torch.cuda.device(E.device):
-        _lib.check(lib.ngcf_spmm_csr_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
-                                         _row_major_ld(out, "out"), _ptr(w), w.numel(), _stream()))
+        if edge_drop is None:
+            _lib.check(lib.ngcf_spmm_csr_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
+                                             _row_major_ld(out, "out"), _ptr(w), w.numel(), _stream()))
+        else:
+            seeds, p, eid = edge_drop
+            arr = (C.c_uint64 * max(len(seeds), 1))(*[int(x) & (2 ** 64 - 1) for x in seeds])
+            _lib.check(lib.ngcf_spmm_csr_dropout_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
+                                                     _row_major_ld(out, "out"), float(p), arr, len(seeds), _ptr(eid),
+                                                     _ptr(w), w.numel(), _stream()))
     return out
 
 
