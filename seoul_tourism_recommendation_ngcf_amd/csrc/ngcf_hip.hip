@@ -83,8 +83,10 @@ struct ngcf_csr {
     int mode = 0;                      // 0/1 row-wise kernels, 2 swept kernel whenever the width allows
     struct Swept {
         int64_t n_owners = 0, n_entries = 0, n_partial = 0, n_heavy = 0;
-        int32_t block_cols = 0, n_blocks = 0, n_rounds = 0;
+        int32_t block_cols = 0, n_blocks = 0, n_rounds = 0, col_lo = 0;
         int64_t *own_ptr = nullptr;        // device [n_owners+1]   entry range of each owner
+        int32_t *own_blk = nullptr;        // device [n_owners][n_blocks] end offset of each column block in that range
+        uint32_t *barrier = nullptr;       // device [8*32] per-XCD arrival counters (zeroed before each launch)
         int32_t *e_col = nullptr;          // device [n_entries]    column, sorted by (column block, row) per owner
         float *e_val = nullptr;            // device [n_entries]
         uint8_t *e_row = nullptr;          // device [n_entries]    owner-local row id (0..15)
@@ -100,6 +102,8 @@ static void free_swept(ngcf_csr *c)
 {
     ngcf_csr::Swept &w = c->swept;
     if (w.own_ptr) (void)hipFree(w.own_ptr);
+    if (w.own_blk) (void)hipFree(w.own_blk);
+    if (w.barrier) (void)hipFree(w.barrier);
     if (w.e_col) (void)hipFree(w.e_col);
     if (w.e_val) (void)hipFree(w.e_val);
     if (w.e_row) (void)hipFree(w.e_row);
@@ -681,20 +685,25 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
 // that fit an XCD's 4 MiB L2 while every CU works on the same block, so a table row is fetched from memory
 // once per XCD and re-used from L2 by the other output rows of that XCD that need it.
 //
-// How: a persistent grid of 256 workgroups (one per CU, 1024 threads, 128 KiB of LDS).  Output rows are handed
-// to "owners"; an owner is a quarter-wave (16 lanes x 16 B = one 64-float slice of a row) that keeps up to 8
+// How: a persistent grid of 256 workgroups (one per CU, 512 threads, 128 KiB of LDS).  Output rows are handed to
+// "owners"; an owner is a quarter-wave (16 lanes x 16 B = one 64-float slice of a row) that keeps up to 16
 // accumulator rows in LDS and walks its own edge list, which the host plan has sorted by (column block, row)
-// and balanced so that every owner has the same work in every block.  All owners start together and advance
-// at the same rate, so they sweep the table together without any cross-workgroup synchronisation (an owner
-// that gets ahead takes the L2 misses for the others, which slows it down again).  Correctness never depends on
-// that: an owner touches nothing but its own LDS rows and adds in list order (deterministic result).
+// and balanced so that every owner has about the same work in every block.  The walk is software-pipelined:
+// list entries are fetched two 16-entry chunks ahead, the 16 gathers of the next chunk are issued before the
+// current chunk is accumulated.  After each column block the workgroups of one XCD (HW_REG_XCC_ID) meet at a
+// counter barrier whose spin is bounded: the barrier only keeps the sweep together for speed, correctness never
+// depends on it (an owner touches nothing but its own LDS rows and adds in list order: deterministic result).
 // Rows longer than the per-owner budget are dealt round-robin to several pieces whose partial sums are combined
 // by spmm_fixup_kernel in a fixed order.  A slice is 64 floats, so d must be a multiple of 64 (other widths use
 // the row-wise kernel); slices and owner rounds are walked one after the other inside the kernel.
+// Status: opt-in (ngcf_csr_set_mode(csr, 2)).  On the C3 item rows it reaches 3.2 ms against 3.5-3.7 ms for the
+// row-wise kernel (69 % L2 hits), still far from the 1.3 ms of a perfectly synchronised sweep: with 8 waves per
+// CU the per-entry run/flush logic and the barrier imbalance dominate.
 // ---------------------------------------------------------------------------------------------
-static const int kSweptRPO = 8;                  // accumulator rows per owner
-static const int kSweptOwnersPerWG = 64;         // 16 waves x 4 quarter-waves
-static const int kSweptWGs = 256;                // one 1024-thread workgroup per CU (128 KiB of LDS)
+static const int kSweptRPO = 16;                 // accumulator rows per owner
+static const int kSweptOwnersPerWG = 32;         // 8 waves x 4 quarter-waves
+static const int kSweptWGs = 256;                // one 512-thread workgroup per CU (128 KiB of LDS)
+static const int kSweptGroups = 8;               // XCDs
 static const int64_t kSweptUnused = INT64_MIN;
 
 static int32_t swept_block_cols()
@@ -792,7 +801,14 @@ static int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     }
     const int64_t n_owners = (int64_t)own_first.size() - 1;
     const int64_t n_owners_pad = align_up(n_owners, per_round);
-    const int64_t n_blocks = (c->n_cols + w.block_cols - 1) / w.block_cols;
+    int32_t col_lo = INT32_MAX, col_hi = 0;
+    for (int64_t x = 0; x < nnz; ++x) {
+        col_lo = std::min(col_lo, col[x]);
+        col_hi = std::max(col_hi, col[x]);
+    }
+    if (nnz == 0) col_lo = 0;
+    w.col_lo = col_lo;
+    const int64_t n_blocks = std::max<int64_t>(1, ((int64_t)col_hi - col_lo + w.block_cols) / w.block_cols);
     std::vector<int64_t> own_ptr((size_t)n_owners_pad + 1, 0);
     std::vector<int64_t> own_dst((size_t)n_owners_pad * kSweptRPO, kSweptUnused);
     for (int64_t o = 0; o < n_owners; ++o) {
@@ -810,6 +826,7 @@ static int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     std::vector<float> e_val((size_t)std::max<int64_t>(nnz, 1));
     std::vector<uint8_t> e_row((size_t)std::max<int64_t>(nnz, 1));
     const int32_t bc = w.block_cols;
+    std::vector<int32_t> own_blk((size_t)n_owners_pad * (size_t)n_blocks, 0);
     parallel_for(n_owners, [&](int64_t lo, int64_t hi) {
         std::vector<int64_t> hist((size_t)n_blocks * kSweptRPO + 1);
         for (int64_t o = lo; o < hi; ++o) {
@@ -817,14 +834,16 @@ static int build_swept_plan(ngcf_csr *c, hipStream_t stream)
             for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
                 const int lr = (int)(i - own_first[o]);
                 for (int64_t x = pieces[i].begin + pieces[i].off; x < pieces[i].end; x += pieces[i].step)
-                    hist[(size_t)(col[x] / bc) * kSweptRPO + lr + 1]++;
+                    hist[(size_t)((col[x] - col_lo) / bc) * kSweptRPO + lr + 1]++;
             }
             for (size_t k = 1; k < hist.size(); ++k) hist[k] += hist[k - 1];
+            for (int64_t bq = 0; bq < n_blocks; ++bq)      // where block bq ends inside this owner's list
+                own_blk[(size_t)o * (size_t)n_blocks + (size_t)bq] = (int32_t)hist[(size_t)(bq + 1) * kSweptRPO];
             const int64_t base = own_ptr[(size_t)o];
             for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
                 const int lr = (int)(i - own_first[o]);
                 for (int64_t x = pieces[i].begin + pieces[i].off; x < pieces[i].end; x += pieces[i].step) {
-                    const int64_t pos = base + hist[(size_t)(col[x] / bc) * kSweptRPO + lr]++;
+                    const int64_t pos = base + hist[(size_t)((col[x] - col_lo) / bc) * kSweptRPO + lr]++;
                     e_col[(size_t)pos] = col[x];
                     e_val[(size_t)pos] = val[x];
                     e_row[(size_t)pos] = (uint8_t)lr;
@@ -852,6 +871,9 @@ static int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     w.n_heavy = (int64_t)heavy_row.size();
     HIP_TRY(hipMalloc(&w.own_ptr, sizeof(int64_t) * own_ptr.size()));
     HIP_TRY(hipMalloc(&w.own_dst, sizeof(int64_t) * own_dst.size()));
+    HIP_TRY(hipMalloc(&w.own_blk, sizeof(int32_t) * own_blk.size()));
+    HIP_TRY(hipMalloc(&w.barrier, sizeof(uint32_t) * 32 * kSweptGroups));
+    HIP_TRY(hipMemcpyAsync(w.own_blk, own_blk.data(), sizeof(int32_t) * own_blk.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMalloc(&w.e_col, sizeof(int32_t) * e_col.size()));
     HIP_TRY(hipMalloc(&w.e_val, sizeof(float) * e_val.size()));
     HIP_TRY(hipMalloc(&w.e_row, e_row.size()));
@@ -880,7 +902,8 @@ template <int U> __device__ inline float row_bcast(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + U, 0xf, 0xf, false));
 }
 
-// add a 16-lane x float4 accumulator into the owner's LDS row
+// add a 16-lane x float4 accumulator into the owner's LDS row (plain read-modify-write: only this quarter-wave
+// ever touches the row; LDS float atomics were measured slower and erratic here)
 __device__ inline void swept_flush(float *__restrict__ rowp, float4 a)
 {
     float4 *p = reinterpret_cast<float4 *>(rowp);
@@ -905,54 +928,88 @@ __device__ inline void swept_flush(float *__restrict__ rowp, float4 a)
 
 #define NGCF_SWEPT_THREADS (kSweptOwnersPerWG * 16)
 
-// One chunk of up to 16 list entries of one owner: all 16 gathers are issued before the first is consumed;
-// consecutive entries of one row are summed in registers and added to the owner's LDS row when the row changes.
-template <bool FULL>
-__device__ inline void swept_chunk(const int32_t *__restrict__ e_col, const float *__restrict__ e_val,
-                                   const uint8_t *__restrict__ e_row, int64_t base, int cnt, int l,
-                                   const float *__restrict__ Es, int64_t ldE, float *__restrict__ myacc, int &cur,
-                                   float4 &a)
+// entries k*16 .. k*16+15 of an owner's list: lane l keeps entry l (column, value, local row)
+struct SweptEntries {
+    int c, r, cnt;
+    float v;
+};
+
+__device__ inline SweptEntries swept_load_entries(const int32_t *__restrict__ e_col, const float *__restrict__ e_val,
+                                                  const uint8_t *__restrict__ e_row, int64_t pos, int64_t end, int l, int idle_col)
 {
-    int c = 0, r = 0;
-    float v = 0.f;
-    if (FULL || l < cnt) {
-        c = e_col[base + l];
-        v = e_val[base + l];
-        r = e_row[base + l];
+    SweptEntries e;
+    const int64_t left = end - pos;
+    e.cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+    e.c = idle_col;
+    e.r = 0;
+    e.v = 0.f;
+    if (l < e.cnt) {
+        e.c = e_col[pos + l];
+        e.v = e_val[pos + l];
+        e.r = e_row[pos + l];
     }
-    if (!FULL) {   // idle slots re-read the chunk's first row (an L2 hit); DPP needs its source lane active
-        const int c0 = row_bcast<0>(c);
-        c = l < cnt ? c : c0;
-    }
-    float4 x[16];
+    return e;
+}
+
+// issue the 16 gathers of a chunk; idle slots re-read the chunk's first row (an L2 hit), never column 0
+__device__ inline void swept_issue(float4 (&x)[16], const SweptEntries &e, int l, const float *__restrict__ Es, int64_t ldE)
+{
+    const int c0 = row_bcast<0>(e.c);
+    const int c = l < e.cnt ? e.c : c0;
 #define NGCF_GATHER(u) x[u] = *reinterpret_cast<const float4 *>(Es + (int64_t)row_bcast<u>(c) * ldE);
     NGCF_GATHER(0) NGCF_GATHER(1) NGCF_GATHER(2) NGCF_GATHER(3) NGCF_GATHER(4) NGCF_GATHER(5) NGCF_GATHER(6) NGCF_GATHER(7)
     NGCF_GATHER(8) NGCF_GATHER(9) NGCF_GATHER(10) NGCF_GATHER(11) NGCF_GATHER(12) NGCF_GATHER(13) NGCF_GATHER(14) NGCF_GATHER(15)
 #undef NGCF_GATHER
+}
+
+// consecutive entries of one row are summed in registers and added to the owner's LDS row when the row changes
+__device__ inline void swept_accumulate(const float4 (&x)[16], const SweptEntries &e, float *__restrict__ myacc, int &cur, float4 &a)
+{
 #define NGCF_ACCUM(u)                                   \
-    if (FULL || u < cnt) {                              \
-        const int rr = row_bcast<u>(r);                 \
+    if (u < e.cnt) {                                    \
+        const int rr = row_bcast<u>(e.r);               \
         if (rr != cur) {                                \
             swept_flush(myacc + cur * 64, a);           \
             a = vzero4();                               \
             cur = rr;                                   \
         }                                               \
-        a = vfma(row_bcast<u>(v), x[u], a);             \
+        a = vfma(row_bcast<u>(e.v), x[u], a);           \
     }
     NGCF_ACCUM(0) NGCF_ACCUM(1) NGCF_ACCUM(2) NGCF_ACCUM(3) NGCF_ACCUM(4) NGCF_ACCUM(5) NGCF_ACCUM(6) NGCF_ACCUM(7)
     NGCF_ACCUM(8) NGCF_ACCUM(9) NGCF_ACCUM(10) NGCF_ACCUM(11) NGCF_ACCUM(12) NGCF_ACCUM(13) NGCF_ACCUM(14) NGCF_ACCUM(15)
 #undef NGCF_ACCUM
 }
 
-__global__ __launch_bounds__(NGCF_SWEPT_THREADS) void spmm_swept_kernel(
-    const int64_t *__restrict__ own_ptr, const int32_t *__restrict__ e_col, const float *__restrict__ e_val,
-    const uint8_t *__restrict__ e_row, const int64_t *__restrict__ own_dst, int n_rounds, int n_slices,
-    const float *__restrict__ E, int64_t ldE, float *__restrict__ out, int64_t ldo, float *__restrict__ partial, int dp)
+// Meeting point of the workgroups of one XCD after a column block.  Bounded spin: a group that is not resident
+// together only loses the L2 re-use; it never hangs and never changes the result.
+__device__ inline void swept_group_sync(unsigned *ctr, unsigned target, int max_spin)
 {
-    __shared__ float acc_lds[kSweptOwnersPerWG * kSweptRPO * 64];   // 128 KiB: 64 owners x 8 rows x 64 floats
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < max_spin)
+            __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NGCF_SWEPT_THREADS) void spmm_swept_kernel(
+    const int64_t *__restrict__ own_ptr, const int32_t *__restrict__ own_blk, const int32_t *__restrict__ e_col,
+    const float *__restrict__ e_val, const uint8_t *__restrict__ e_row, const int64_t *__restrict__ own_dst, int n_rounds,
+    int n_blocks, int n_slices, const float *__restrict__ E, int64_t ldE, float *__restrict__ out, int64_t ldo,
+    float *__restrict__ partial, int dp, unsigned *bar, int max_spin)
+{
+    __shared__ float acc_lds[kSweptOwnersPerWG * kSweptRPO * 64 + 4];   // 128 KiB of accumulators (+ the XCD id)
     const int q = threadIdx.x >> 4;          // owner slot in the workgroup
     const int l = threadIdx.x & 15;          // lane in the quarter-wave
     float *myacc = acc_lds + q * (kSweptRPO * 64) + l * 4;
+    if (threadIdx.x == 0)
+        reinterpret_cast<unsigned *>(acc_lds)[kSweptOwnersPerWG * kSweptRPO * 64] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    __syncthreads();
+    unsigned *ctr = bar + reinterpret_cast<unsigned *>(acc_lds)[kSweptOwnersPerWG * kSweptRPO * 64] * 32;   // HW_REG_XCC_ID
+    const unsigned members = gridDim.x / kSweptGroups;
+    unsigned seq = 0;
     for (int slice = 0; slice < n_slices; ++slice) {
         const float *Es = E + slice * 64 + l * 4;
         for (int round = 0; round < n_rounds; ++round) {
@@ -960,11 +1017,54 @@ __global__ __launch_bounds__(NGCF_SWEPT_THREADS) void spmm_swept_kernel(
 #pragma unroll
             for (int r = 0; r < kSweptRPO; ++r) *reinterpret_cast<float4 *>(myacc + r * 64) = vzero4();
             const int64_t beg = own_ptr[owner], end = own_ptr[owner + 1];
-            int cur = 0;
+            const int32_t *blk = own_blk + owner * (int64_t)n_blocks;
+            // chunks this WAVE walks: the longest of its four owners
+            int my_chunks = (int)((end - beg + 15) >> 4);
+            my_chunks = max(my_chunks, __shfl_xor(my_chunks, 16));
+            my_chunks = max(my_chunks, __shfl_xor(my_chunks, 32));
+            int cur = 0, b = 0;
+            int bend = n_blocks > 0 ? blk[0] : 0x7fffffff;     // end of block b in this owner's list (kept one block ahead)
             float4 a = vzero4();
-            int64_t base = beg;
-            for (; base + 16 <= end; base += 16) swept_chunk<true>(e_col, e_val, e_row, base, 16, l, Es, ldE, myacc, cur, a);
-            if (base < end) swept_chunk<false>(e_col, e_val, e_row, base, (int)(end - base), l, Es, ldE, myacc, cur, a);
+            int idle_col = end > beg ? e_col[beg] : 0;
+            // software pipeline: entries two chunks ahead, gathers one chunk ahead of the accumulation
+            float4 xA[16], xB[16];
+            SweptEntries eA = swept_load_entries(e_col, e_val, e_row, beg, end, l, idle_col);
+            SweptEntries eB = swept_load_entries(e_col, e_val, e_row, beg + 16, end, l, idle_col);
+            swept_issue(xA, eA, l, Es, ldE);
+            for (int k = 0; k < my_chunks; k += 2) {
+                // ---- chunk k (set A): prefetch entries k+2, issue gathers k+1, accumulate k
+                SweptEntries eC = swept_load_entries(e_col, e_val, e_row, beg + (int64_t)(k + 2) * 16, end, l, idle_col);
+                swept_issue(xB, eB, l, Es, ldE);
+                swept_accumulate(xA, eA, myacc, cur, a);
+                // a column block is finished once every owner of the wave has walked past its end
+                while (b < n_blocks) {
+                    int done = bend <= (k + 1) * 16 ? 1 : 0;
+                    done &= __shfl_xor(done, 16);
+                    done &= __shfl_xor(done, 32);
+                    if (!done) break;
+                    swept_group_sync(ctr, members * (++seq), max_spin);
+                    ++b;
+                    bend = b < n_blocks ? blk[b] : 0x7fffffff;
+                }
+                // ---- chunk k+1 (set B)
+                eA = swept_load_entries(e_col, e_val, e_row, beg + (int64_t)(k + 3) * 16, end, l, idle_col);
+                swept_issue(xA, eC, l, Es, ldE);
+                swept_accumulate(xB, eB, myacc, cur, a);
+                while (b < n_blocks) {
+                    int done = bend <= (k + 2) * 16 ? 1 : 0;
+                    done &= __shfl_xor(done, 16);
+                    done &= __shfl_xor(done, 32);
+                    if (!done) break;
+                    swept_group_sync(ctr, members * (++seq), max_spin);
+                    ++b;
+                    bend = b < n_blocks ? blk[b] : 0x7fffffff;
+                }
+                eB = eA;
+                eA = eC;
+                // rotate: next iteration accumulates chunk k+2 from xA (issued above from eC) with entries eA = eC,
+                // and needs eB = entries k+3
+            }
+            for (; b < n_blocks; ++b) swept_group_sync(ctr, members * (++seq), max_spin);   // every wave meets n_blocks times
             swept_flush(myacc + cur * 64, a);
             // write the owner's rows (its own LDS rows only: no barrier needed)
 #pragma unroll 1
@@ -1123,9 +1223,12 @@ static int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, 
                 return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
             partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
         }
+        static const int max_spin = getenv("NGCF_SWEPT_SPIN") ? atoi(getenv("NGCF_SWEPT_SPIN")) : 400;
+        HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * kSweptGroups, stream));
         prof_mark(stream, 0);
-        spmm_swept_kernel<<<dim3(kSweptWGs), NGCF_SWEPT_THREADS, 0, stream>>>(w.own_ptr, w.e_col, w.e_val, w.e_row, w.own_dst,
-                                                                              w.n_rounds, d / 64, E, ldE, out, ldo, partial, dp);
+        spmm_swept_kernel<<<dim3(kSweptWGs), NGCF_SWEPT_THREADS, 0, stream>>>(
+            w.own_ptr, w.own_blk, w.e_col, w.e_val, w.e_row, w.own_dst, w.n_rounds, w.n_blocks, d / 64, E, ldE, out, ldo,
+            partial, dp, w.barrier, max_spin);
         LAUNCH_CHECK();
         prof_mark(stream, 1);
         if (w.n_heavy > 0) {
