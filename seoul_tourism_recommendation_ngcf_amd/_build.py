@@ -10,8 +10,10 @@ import shutil
 import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG_DIR, "csrc", "ngcf_hip.hip")
-HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "ngcf_hip.h")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SOURCES = [os.path.join(CSRC, f) for f in ("csr.hip", "spmm.hip", "spmm_swept.hip", "dense.hip", "ops.hip", "backward.hip")]
+HEADERS = [os.path.join(os.path.dirname(PKG_DIR), "include", "ngcf_hip.h"), os.path.join(CSRC, "common.h"),
+           os.path.join(CSRC, "spmm_device.h")]
 LIB = os.path.join(PKG_DIR, "libngcf_hip.so")
 ARCH = "gfx950"
 
@@ -27,15 +29,15 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in (SRC, HEADER))
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/ngcf_hip.hip -> libngcf_hip.so for gfx950.  Returns the library path."""
+    """Compile csrc/*.hip -> libngcf_hip.so for gfx950 (one hipcc call).  Returns the library path."""
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", "-o", LIB + ".tmp", SRC]
+           "-Wall", "-Wno-unused-function", "-o", LIB + ".tmp"] + SOURCES
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

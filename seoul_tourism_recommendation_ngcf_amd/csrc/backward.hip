@@ -1,0 +1,209 @@
+// backward.hip - kernels of the backward pass.
+#include "common.h"
+
+// =============================================================================================
+// Backward pass (`loss.backward()` in experiment.py:57).
+// The two plain GEMMs per layer (dM.[W1|W2] and dM^T.[S|P]) are library GEMMs issued by the host; everything
+// around them is fused here: BPR gradient, gather scatter-add, normalise/dropout/LeakyReLU backward,
+// the [LE+E | LE*E] operand, and the combination of the GEMM result into dLE and the direct part of dE.
+// =============================================================================================
+
+// ---- BPR backward (bprloss.py:15-22) ----------------------------------------------------------
+// loss = (-sum logsig(|u.p| - |u.n|) + wd (|u|^2 + |p|^2 + |n|^2)) / bs ; one wave per row
+__global__ __launch_bounds__(256) void bpr_backward_kernel(const float *__restrict__ u, int64_t Bu,
+                                                           const float *__restrict__ p, int64_t Bp,
+                                                           const float *__restrict__ n, int64_t Bn, int64_t R, int D,
+                                                           float wd, float batch_size, const float *__restrict__ gout,
+                                                           float *__restrict__ du, float *__restrict__ dp,
+                                                           float *__restrict__ dn)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float g = gout[0] / batch_size;
+    const int64_t ru = Bu == 1 ? 0 : r, rp = Bp == 1 ? 0 : r, rn = Bn == 1 ? 0 : r;
+    const float *ur = u + ru * D, *pr = p + rp * D, *nr = n + rn * D;
+    float up = 0.f, un = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        up = fmaf(ur[j], pr[j], up);
+        un = fmaf(ur[j], nr[j], un);
+    }
+    up = wave_sum(up);
+    un = wave_sum(un);
+    const float x = fabsf(up) - fabsf(un);
+    const float s = -1.f / (1.f + expf(x));                  // d(-logsigmoid(x))/dx = -sigmoid(-x)
+    const float sp = up > 0.f ? 1.f : (up < 0.f ? -1.f : 0.f);   // d|t|/dt, 0 at 0 like torch.abs
+    const float sn = un > 0.f ? 1.f : (un < 0.f ? -1.f : 0.f);
+    const float two_wd = 2.f * wd;
+    for (int j = lane; j < D; j += 64) {
+        const float a = ur[j], b = pr[j], c = nr[j];
+        // the weight-decay term of a broadcast row is counted once (its own single row)
+        const float gu = g * (s * (sp * b - sn * c) + ((Bu == 1 && r > 0) ? 0.f : two_wd * a));
+        const float gp = g * (s * sp * a + ((Bp == 1 && r > 0) ? 0.f : two_wd * b));
+        const float gn = g * (-s * sn * a + ((Bn == 1 && r > 0) ? 0.f : two_wd * c));
+        if (Bu == R) du[ru * D + j] = gu; else atomicAdd(&du[j], gu);
+        if (Bp == R) dp[rp * D + j] = gp; else atomicAdd(&dp[j], gp);
+        if (Bn == R) dn[rn * D + j] = gn; else atomicAdd(&dn[j], gn);
+    }
+}
+
+extern "C" int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, const float *n, int64_t Bn,
+                                     int D, float wd, float batch_size, const float *grad_out, float *du, float *dp,
+                                     float *dn, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!u || !p || !n || !grad_out || !du || !dp || !dn || D <= 0) return fail(NGCF_ERR_ARG, "bpr_backward: null argument");
+    const int64_t R = std::max(Bu, std::max(Bp, Bn));
+    if (R < 1 || (Bu != 1 && Bu != R) || (Bp != 1 && Bp != R) || (Bn != 1 && Bn != R))
+        return fail(NGCF_ERR_ARG, "bpr_backward: row counts %lld/%lld/%lld do not broadcast", (long long)Bu, (long long)Bp, (long long)Bn);
+    if (Bu != R) HIP_TRY(hipMemsetAsync(du, 0, sizeof(float) * (size_t)D, stream));
+    if (Bp != R) HIP_TRY(hipMemsetAsync(dp, 0, sizeof(float) * (size_t)D, stream));
+    if (Bn != R) HIP_TRY(hipMemsetAsync(dn, 0, sizeof(float) * (size_t)D, stream));
+    bpr_backward_kernel<<<dim3((unsigned)((R + 3) / 4)), 256, 0, stream>>>(u, Bu, p, Bp, n, Bn, R, D, wd, batch_size, grad_out,
+                                                                            du, dp, dn);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---- gather backward: G[row_off + idx[b], :] += g[b, :] (duplicates add up) -------------------
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float *__restrict__ G, int64_t ld, int d,
+                                                               const int64_t *__restrict__ idx, int64_t B, int64_t row_off,
+                                                               int64_t n_idx_rows, const float *__restrict__ g, int64_t ldg)
+{
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t i = idx[b];
+    if (i < 0 || i >= n_idx_rows) return;
+    float *dst = G + (row_off + i) * ld;
+    for (int j = threadIdx.x & 63; j < d; j += 64) atomicAdd(&dst[j], g[b * ldg + j]);
+}
+
+extern "C" int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, int64_t B, int64_t row_off,
+                                         int64_t n_idx_rows, const float *g, int64_t ldg, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B == 0) return NGCF_OK;
+    if (!G || !idx || !g || d <= 0 || ld < d || ldg < d) return fail(NGCF_ERR_ARG, "scatter_add_rows: bad argument");
+    scatter_add_rows_kernel<<<dim3((unsigned)((B + 3) / 4)), 256, 0, stream>>>(G, ld, d, idx, B, row_off, n_idx_rows, g, ldg);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---- normalise + dropout + LeakyReLU backward: (dN, dC, C) -> dM, one wave per row ------------
+// forward: A = leaky(M); C = keep ? A/(1-p) : 0; N = C / max(|C|, eps)    (NGCF.py:140-144)
+__global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restrict__ dN, int64_t ldn,
+                                                            const float *__restrict__ dC, int64_t ldc,
+                                                            const float *__restrict__ C, int64_t ldC, int64_t n_rows,
+                                                            int d, float leaky, float drop_p, uint64_t seed,
+                                                            float *__restrict__ dM, int64_t ldm)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *c = C + r * ldC, *g = dN + r * ldn;
+    float ss = 0.f, dot = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        ss = fmaf(c[j], c[j], ss);
+        dot = fmaf(c[j], g[j], dot);
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float nrm = sqrtf(ss);
+    const bool clamped = nrm < 1e-12f;                       // F.normalize's clamp_min: N = C / eps there
+    const float den = clamped ? 1e-12f : nrm;
+    const float ydot = clamped ? 0.f : dot / (den * den);    // (y.dy)/|x| with y = x/|x|
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    for (int j = lane; j < d; j += 64) {
+        float t = g[j] / den - c[j] * (ydot / den);
+        if (dC) t += dC[r * ldc + j];
+        if (drop_p > 0.f) {
+            const uint32_t h = mix32(seed ^ ((uint64_t)r * 0x9E3779B97F4A7C15ULL + (uint64_t)j));
+            t = h < thr ? 0.f : t * keep_scale;
+        }
+        dM[r * ldm + j] = t * (c[j] > 0.f ? 1.f : leaky);     // sign(C) == sign(M) wherever C was kept
+    }
+}
+
+extern "C" int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
+                                      int64_t n_rows, int d, float leaky, float drop_p, uint64_t seed, float *dM, int64_t ldm,
+                                      void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows == 0) return NGCF_OK;
+    if (!dN || !C || !dM || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_pre: bad argument");
+    layer_bwd_pre_kernel<<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
+                                                                                 seed, dM, ldm);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---- SP = [LE + E | LE * E]  (the GEMM operand of the forward, needed for dW1/dW2) ------------
+__global__ void sp_concat_kernel(const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ E, int64_t ldE,
+                                 int64_t n_rows, int d, float *__restrict__ SP)
+{
+    const int64_t total = n_rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d;
+        const int j = (int)(i % d);
+        const float a = LE[r * ldLE + j], b = E[r * ldE + j];
+        SP[r * 2 * d + j] = a + b;
+        SP[r * 2 * d + d + j] = a * b;
+    }
+}
+
+extern "C" int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ldE, int64_t n_rows, int d, float *SP,
+                                  void *stream_)
+{
+    if (n_rows == 0) return NGCF_OK;
+    if (!LE || !E || !SP || d <= 0) return fail(NGCF_ERR_ARG, "sp_concat: bad argument");
+    sp_concat_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(LE, ldLE, E, ldE, n_rows, d, SP);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// ---- dSP = dM.[W1 | W2] -> dLE = dS + dP*E ; dE_direct = dS + dP*LE ----------------------------
+__global__ void layer_bwd_combine_kernel(const float *__restrict__ dSP, const float *__restrict__ LE, int64_t ldLE,
+                                         const float *__restrict__ E, int64_t ldE, int64_t n_rows, int d,
+                                         float *__restrict__ dLE, float *__restrict__ dE)
+{
+    const int64_t total = n_rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d;
+        const int j = (int)(i % d);
+        const float ds = dSP[r * 2 * d + j], dp = dSP[r * 2 * d + d + j];
+        dLE[i] = fmaf(dp, E[r * ldE + j], ds);
+        dE[i] = fmaf(dp, LE[r * ldLE + j], ds);
+    }
+}
+
+extern "C" int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
+                                          int64_t n_rows, int d, float *dLE, float *dE, void *stream_)
+{
+    if (n_rows == 0) return NGCF_OK;
+    if (!dSP || !LE || !E || !dLE || !dE || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_combine: bad argument");
+    layer_bwd_combine_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(dSP, LE, ldLE, E, ldE, n_rows, d, dLE, dE);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+// out[r, :] += add[r, :]   (dE = dE_direct + L^T.dLE accumulation)
+__global__ void add_rows_kernel(float *__restrict__ out, int64_t ldo, const float *__restrict__ add, int64_t lda, int64_t n_rows, int d)
+{
+    const int64_t total = n_rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d;
+        const int j = (int)(i % d);
+        out[r * ldo + j] += add[r * lda + j];
+    }
+}
+
+extern "C" int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream_)
+{
+    if (n_rows == 0) return NGCF_OK;
+    if (!out || !add || d <= 0) return fail(NGCF_ERR_ARG, "add_rows: bad argument");
+    add_rows_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(out, ldo, add, lda, n_rows, d);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+

@@ -1,0 +1,330 @@
+// csr.hip - library identity, the Laplacian CSR object, its row-segment plan and row groups.
+//
+// Kernels (all fp32, wave = 64 lanes):
+//   spmm / spmm_fixup                    : row-segmented CSR SpMM  LE = L.E          (NGCF.py:130)
+//   pack_weights                         : [W1^T ; W2^T] chunk-interleaved + 2*b1+b2  (NGCF.py:131-138)
+//   layer_dense                          : fp32-MFMA GEMM + bias + LeakyReLU + (dropout) +
+//                                          row L2-normalise, writes carry and all_E block (NGCF.py:131-146)
+//   feature_inject (3 small kernels)     : NGCF.py:103-115
+//   gather_rows                          : NGCF.py:151-155
+//   bpr_rows / bpr_finish                : bprloss.py:15-22
+// gfx950 only: no other architecture, no compatibility paths.
+#include "common.h"
+
+extern "C" const char *ngcf_last_error(void) { return g_err; }
+extern "C" const char *ngcf_target_arch(void) { return "gfx950"; }
+extern "C" int ngcf_version(void) { return 1; }
+
+
+static void free_plan(ngcf_csr *c)
+{
+    if (c->seg_row) (void)hipFree(c->seg_row);
+    if (c->seg_begin) (void)hipFree(c->seg_begin);
+    if (c->heavy_row) (void)hipFree(c->heavy_row);
+    if (c->heavy_seg_ptr) (void)hipFree(c->heavy_seg_ptr);
+    c->seg_row = nullptr;
+    c->seg_begin = nullptr;
+    c->heavy_row = nullptr;
+    c->heavy_seg_ptr = nullptr;
+    c->n_seg = c->n_heavy = 0;
+}
+
+extern "C" void ngcf_csr_free(ngcf_csr_t *c)
+{
+    if (!c) return;
+    free_plan(c);
+    free_swept(c);
+    if (c->owns) {
+        if (c->rowptr) (void)hipFree(c->rowptr);
+        if (c->colidx) (void)hipFree(c->colidx);
+        if (c->vals) (void)hipFree(c->vals);
+    }
+    delete c;
+}
+
+extern "C" int64_t ngcf_csr_nnz(const ngcf_csr_t *c) { return c ? c->nnz : -1; }
+extern "C" int64_t ngcf_csr_n_rows(const ngcf_csr_t *c) { return c ? c->n_rows : -1; }
+extern "C" int64_t ngcf_csr_n_cols(const ngcf_csr_t *c) { return c ? c->n_cols : -1; }
+extern "C" int64_t ngcf_csr_n_segments(const ngcf_csr_t *c) { return c ? c->n_seg : -1; }
+extern "C" const int64_t *ngcf_csr_rowptr(const ngcf_csr_t *c) { return c ? c->rowptr : nullptr; }
+extern "C" const int32_t *ngcf_csr_colidx(const ngcf_csr_t *c) { return c ? c->colidx : nullptr; }
+extern "C" const float *ngcf_csr_vals(const ngcf_csr_t *c) { return c ? c->vals : nullptr; }
+
+// flags[0] |= 1 when rows are not non-decreasing; flags[1] |= 1 when an id is out of range
+__global__ void coo_check_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+                                 int64_t nnz, int64_t n_rows, int64_t n_cols, int32_t *flags)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool unsorted = false, bad = false;
+    for (; i < nnz; i += stride) {
+        const int64_t r = rows[i], c = cols[i];
+        bad |= (r < 0) | (r >= n_rows) | (c < 0) | (c >= n_cols);
+        if (i + 1 < nnz) unsorted |= rows[i + 1] < r;
+    }
+    if (unsorted) atomicOr(&flags[0], 1);
+    if (bad) atomicOr(&flags[1], 1);
+}
+
+// rowptr[r] = first entry whose row id is >= r (rows sorted); one thread per r in [0, n_rows]
+__global__ void coo_rowptr_kernel(const int64_t *__restrict__ rows, int64_t nnz, int64_t n_rows,
+                                  int64_t *__restrict__ rowptr)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rows[mid] < r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    rowptr[r] = lo;
+}
+
+__global__ void coo_copy_kernel(const int64_t *__restrict__ cols, const float *__restrict__ vals, int64_t nnz,
+                                int32_t *__restrict__ colidx, float *__restrict__ out_vals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nnz; i += stride) {
+        colidx[i] = (int32_t)cols[i];
+        out_vals[i] = vals[i];
+    }
+}
+
+
+// per 1024-row block: smallest and largest column any of its rows gathers (one-time, plan only)
+#define NGCF_GROUP_ROWS 1024
+__global__ void row_colrange_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                    int64_t n_rows, int32_t *__restrict__ blk_min, int32_t *__restrict__ blk_max)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    int32_t lo = INT32_MAX, hi = -1;
+    for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+        const int32_t c = colidx[e];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+    if (hi >= 0) {
+        atomicMin(&blk_min[row / NGCF_GROUP_ROWS], lo);
+        atomicMax(&blk_max[row / NGCF_GROUP_ROWS], hi);
+    }
+}
+
+// A row block is "sliceable" when one 32-float slice (128 B) of every row it gathers is at most 48 MiB: then the
+// hot part of the table slice lives in the XCD L2s while a slice-major launch walks it (measured on the user half
+// of C3: 2.33 ms sliced vs 2.98 ms unsliced; the 1 M-row user table gets slower sliced: 3.8 vs 3.46 ms).
+static const int64_t kSliceFootprintRows = (48ll << 20) / 128;
+
+static int build_row_groups(ngcf_csr *c, hipStream_t stream)
+{
+    c->groups.clear();
+    if (c->n_rows == 0) return NGCF_OK;
+    const int64_t nb = (c->n_rows + NGCF_GROUP_ROWS - 1) / NGCF_GROUP_ROWS;
+    int32_t *d_min = nullptr, *d_max = nullptr;
+    std::vector<int32_t> h_min((size_t)nb), h_max((size_t)nb);
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&d_min, sizeof(int32_t) * (size_t)nb));
+        HIP_TRY(hipMalloc(&d_max, sizeof(int32_t) * (size_t)nb));
+        HIP_TRY(hipMemsetAsync(d_min, 0x7f, sizeof(int32_t) * (size_t)nb, stream));   // 0x7f7f7f7f: large
+        HIP_TRY(hipMemsetAsync(d_max, 0xff, sizeof(int32_t) * (size_t)nb, stream));   // -1
+        row_colrange_kernel<<<(int)((c->n_rows + 255) / 256), 256, 0, stream>>>(c->rowptr, c->colidx, c->n_rows, d_min, d_max);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(h_min.data(), d_min, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_max.data(), d_max, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return NGCF_OK;
+    };
+    const int rc = body();
+    if (d_min) (void)hipFree(d_min);
+    if (d_max) (void)hipFree(d_max);
+    if (rc != NGCF_OK) return rc;
+    for (int64_t b = 0; b < nb; ++b) {
+        const bool s = h_max[(size_t)b] < 0 || (int64_t)h_max[(size_t)b] - h_min[(size_t)b] + 1 <= kSliceFootprintRows;
+        const int64_t lo = b * NGCF_GROUP_ROWS, hi = std::min<int64_t>(c->n_rows, lo + NGCF_GROUP_ROWS);
+        if (!c->groups.empty() && c->groups.back().sliceable == s)
+            c->groups.back().end = hi;
+        else
+            c->groups.push_back({lo, hi, s});
+    }
+    // a group of a few blocks is not worth its own launch: give it its neighbour's class, then fuse equal neighbours
+    for (size_t i = 0; i < c->groups.size(); ++i)
+        if (c->groups.size() > 1 && c->groups[i].end - c->groups[i].begin < 16 * NGCF_GROUP_ROWS)
+            c->groups[i].sliceable = c->groups[i > 0 ? i - 1 : i + 1].sliceable;
+    for (size_t k = 1; k < c->groups.size();) {
+        if (c->groups[k].sliceable == c->groups[k - 1].sliceable) {
+            c->groups[k - 1].end = c->groups[k].end;
+            c->groups.erase(c->groups.begin() + (long)k);
+        } else {
+            ++k;
+        }
+    }
+    return NGCF_OK;
+}
+
+
+extern "C" int ngcf_csr_plan(ngcf_csr_t *c, int32_t seg_len, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c) return fail(NGCF_ERR_ARG, "ngcf_csr_plan: null csr");
+    if (seg_len < 64) return fail(NGCF_ERR_ARG, "ngcf_csr_plan: seg_len must be >= 64 (got %d)", seg_len);
+    free_plan(c);
+    c->seg_len = seg_len;
+    std::vector<int64_t> rp((size_t)c->n_rows + 1);
+    HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int32_t> seg_row, heavy_row;
+    std::vector<int64_t> seg_begin, heavy_ptr;
+    heavy_ptr.push_back(0);
+    for (int64_t r = 0; r < c->n_rows; ++r) {
+        const int64_t len = rp[r + 1] - rp[r];
+        if (len > seg_len) {
+            heavy_row.push_back((int32_t)r);
+            for (int64_t b = rp[r]; b < rp[r + 1]; b += seg_len) {
+                seg_row.push_back((int32_t)r);
+                seg_begin.push_back(b);
+            }
+            heavy_ptr.push_back((int64_t)seg_row.size());
+        }
+    }
+    c->n_seg = (int64_t)seg_row.size();
+    c->n_heavy = (int64_t)heavy_row.size();
+    if (c->n_seg > 0) {
+        HIP_TRY(hipMalloc(&c->seg_row, sizeof(int32_t) * seg_row.size()));
+        HIP_TRY(hipMalloc(&c->seg_begin, sizeof(int64_t) * seg_begin.size()));
+        HIP_TRY(hipMalloc(&c->heavy_row, sizeof(int32_t) * heavy_row.size()));
+        HIP_TRY(hipMalloc(&c->heavy_seg_ptr, sizeof(int64_t) * heavy_ptr.size()));
+        HIP_TRY(hipMemcpyAsync(c->seg_row, seg_row.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->seg_begin, seg_begin.data(), sizeof(int64_t) * seg_begin.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->heavy_row, heavy_row.data(), sizeof(int32_t) * heavy_row.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->heavy_seg_ptr, heavy_ptr.data(), sizeof(int64_t) * heavy_ptr.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    {
+        const int rc = build_row_groups(c, stream);
+        if (rc != NGCF_OK) return rc;
+    }
+    if (c->swept.n_owners == 0 && c->mode == 2) return build_swept_plan(c, stream);
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_csr_set_mode(ngcf_csr_t *c, int mode, void *stream)
+{
+    if (!c || mode < 0 || mode > 2) return fail(NGCF_ERR_ARG, "ngcf_csr_set_mode: bad argument");
+    c->mode = mode;
+    if (mode != 2) {
+        free_swept(c);
+        return NGCF_OK;
+    }
+    if (c->swept.n_owners == 0) return build_swept_plan(c, (hipStream_t)stream);
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx, const float *vals,
+                                    int64_t n_rows, int64_t n_cols, int64_t nnz, ngcf_csr_t **out, void *stream)
+{
+    if (!out) return fail(NGCF_ERR_ARG, "ngcf_csr_from_arrays: null out");
+    *out = nullptr;
+    if (!rowptr || (nnz > 0 && (!colidx || !vals)))
+        return fail(NGCF_ERR_ARG, "ngcf_csr_from_arrays: null array");
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_cols >= (int64_t)1 << 31 || n_rows >= (int64_t)1 << 31)
+        return fail(NGCF_ERR_ARG, "ngcf_csr_from_arrays: bad shape %lld x %lld nnz %lld", (long long)n_rows,
+                    (long long)n_cols, (long long)nnz);
+    ngcf_csr *c = new ngcf_csr();
+    c->n_rows = n_rows;
+    c->n_cols = n_cols;
+    c->nnz = nnz;
+    c->rowptr = const_cast<int64_t *>(rowptr);
+    c->colidx = const_cast<int32_t *>(colidx);
+    c->vals = const_cast<float *>(vals);
+    c->owns = false;
+    const int rc = ngcf_csr_plan(c, kDefaultSegLen, stream);
+    if (rc != NGCF_OK) {
+        ngcf_csr_free(c);
+        return rc;
+    }
+    *out = c;
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_csr_from_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz,
+                                 int64_t n_rows, int64_t n_cols, ngcf_csr_t **out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) return fail(NGCF_ERR_ARG, "ngcf_csr_from_coo: null out");
+    *out = nullptr;
+    if (nnz < 0 || n_rows < 0 || n_cols < 0 || n_cols >= (int64_t)1 << 31 || n_rows >= (int64_t)1 << 31)
+        return fail(NGCF_ERR_ARG, "ngcf_csr_from_coo: bad shape %lld x %lld nnz %lld", (long long)n_rows,
+                    (long long)n_cols, (long long)nnz);
+    if (nnz > 0 && (!rows || !cols || !vals)) return fail(NGCF_ERR_ARG, "ngcf_csr_from_coo: null array");
+
+    ngcf_csr *c = new ngcf_csr();
+    c->n_rows = n_rows;
+    c->n_cols = n_cols;
+    c->nnz = nnz;
+    c->owns = true;
+    int32_t *flags = nullptr;
+    int rc = NGCF_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&c->rowptr, sizeof(int64_t) * (size_t)(n_rows + 1)));
+        HIP_TRY(hipMalloc(&c->colidx, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+        HIP_TRY(hipMalloc(&c->vals, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1)));
+        HIP_TRY(hipMalloc(&flags, 2 * sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), stream));
+        int32_t h_flags[2] = {0, 0};
+        if (nnz > 0) {
+            coo_check_kernel<<<grid_for(nnz, 256), 256, 0, stream>>>(rows, cols, nnz, n_rows, n_cols, flags);
+            LAUNCH_CHECK();
+        }
+        HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h_flags[1])
+            return fail(NGCF_ERR_INDEX, "ngcf_csr_from_coo: index out of range for a %lld x %lld matrix",
+                        (long long)n_rows, (long long)n_cols);
+        if (!h_flags[0]) {
+            // rows already sorted (what matrix.py:79-83 emits): convert on the device
+            coo_rowptr_kernel<<<(int)((n_rows + 1 + 255) / 256), 256, 0, stream>>>(rows, nnz, n_rows, c->rowptr);
+            LAUNCH_CHECK();
+            if (nnz > 0) {
+                coo_copy_kernel<<<grid_for(nnz, 256), 256, 0, stream>>>(cols, vals, nnz, c->colidx, c->vals);
+                LAUNCH_CHECK();
+            }
+        } else {
+            // unsorted input: stable sort by row on the host (one-time set-up path)
+            std::vector<int64_t> hr((size_t)nnz), hc((size_t)nnz);
+            std::vector<float> hv((size_t)nnz);
+            HIP_TRY(hipMemcpyAsync(hr.data(), rows, sizeof(int64_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(hc.data(), cols, sizeof(int64_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(hv.data(), vals, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<int64_t> rp((size_t)n_rows + 1, 0);
+            for (int64_t i = 0; i < nnz; ++i) rp[(size_t)hr[i] + 1]++;
+            for (int64_t r = 0; r < n_rows; ++r) rp[(size_t)r + 1] += rp[(size_t)r];
+            std::vector<int64_t> cur(rp.begin(), rp.end() - 1);
+            std::vector<int32_t> oc((size_t)nnz);
+            std::vector<float> ov((size_t)nnz);
+            for (int64_t i = 0; i < nnz; ++i) {   // counting sort = stable
+                const int64_t dst = cur[(size_t)hr[i]]++;
+                oc[(size_t)dst] = (int32_t)hc[i];
+                ov[(size_t)dst] = hv[i];
+            }
+            HIP_TRY(hipMemcpyAsync(c->rowptr, rp.data(), sizeof(int64_t) * rp.size(), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(c->colidx, oc.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(c->vals, ov.data(), sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return ngcf_csr_plan(c, kDefaultSegLen, stream);
+    };
+    rc = body();
+    if (flags) (void)hipFree(flags);
+    if (rc != NGCF_OK) {
+        ngcf_csr_free(c);
+        return rc;
+    }
+    *out = c;
+    return NGCF_OK;
+}
+

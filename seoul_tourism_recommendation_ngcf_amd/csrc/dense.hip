@@ -1,0 +1,343 @@
+// dense.hip - the dense half of a layer on the fp32 matrix cores, and the fused layer entry point.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Dense half of a layer (NGCF.py:131-146) on the fp32 matrix cores.
+//
+//   M = [LE+E | LE*E] . [W1^T ; W2^T] + (2*b1 + b2)
+// The K dimension is walked in chunks of DC = 16 input columns: a chunk contributes 16 "sum" values
+// and 16 "product" values per row (KC = 32 k-steps), so LE and E are read exactly once.  Weights are
+// packed per call into that chunk order ([n_chunks*32][DOP], zero padded) by pack_weights_kernel.
+// v_mfma_f32_32x32x2_f32: exact fp32 FMA chain per output element.
+// A workgroup of 4 waves owns BM = 32*RW full rows; waves are arranged RW x CW, each wave NT 32x32 tiles,
+// so a whole output row (<= 32*NT*CW columns) lives in one workgroup and the L2 row-normalisation is
+// done in registers + one LDS exchange.
+// ---------------------------------------------------------------------------------------------
+#define NGCF_KC 32
+#define NGCF_DC 16
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers inside lambdas
+
+__global__ void pack_weights_kernel(const float *__restrict__ W1, const float *__restrict__ b1,
+                                    const float *__restrict__ W2, const float *__restrict__ b2, int d_in, int d_out,
+                                    int n_chunks, int DOP, int NT, float *__restrict__ Wt, float *__restrict__ bias2)
+{
+    // Wt[chunk][kl][cw][j][t] = weight of output column (cw*NT + t)*32 + j: a lane reads its NT tile values at once
+    const int total = n_chunks * NGCF_KC * DOP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int within = i % DOP;
+        const int t = within % NT, j = (within / NT) % 32, cw = within / (NT * 32);
+        const int oc = (cw * NT + t) * 32 + j;
+        const int k = i / DOP;
+        const int chunk = k / NGCF_KC, kl = k % NGCF_KC;
+        const int col = chunk * NGCF_DC + (kl % NGCF_DC);
+        float w = 0.f;
+        if (oc < d_out && col < d_in) w = (kl < NGCF_DC ? W1 : W2)[(int64_t)oc * d_in + col];
+        Wt[i] = w;
+    }
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < DOP; j += gridDim.x * blockDim.x)
+        bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
+}
+
+template <int RW, int CW, int NT, bool ALIGNED>
+__global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restrict__ LE, int64_t ldLE,
+                                                          const float *__restrict__ Es, int64_t ldE, int64_t n_rows,
+                                                          int d_in, int d_out, const float *__restrict__ Wt,
+                                                          const float *__restrict__ bias2, int n_chunks,
+                                                          float leaky, float drop_p, uint64_t drop_seed,
+                                                          float *__restrict__ carry, int64_t ldc,
+                                                          float *__restrict__ norm, int64_t ldn)
+{
+    constexpr int BM = 32 * RW;
+    constexpr int WCOLS = 32 * NT * CW;      // == DOP
+    constexpr int XLD = NGCF_KC + 4;         // 36: rows stay 16-B aligned and b128 column reads are conflict-free
+    constexpr bool DB = WCOLS <= 128;        // double-buffered LDS (one barrier per chunk) where two blocks still fit a CU
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int RR = (BM + 63) / 64;       // X rows staged per thread
+    constexpr int WN = (NGCF_KC * WCOLS / 4) / 256;   // W float4s staged per thread
+    __shared__ float Xs[NBUF * BM * XLD];
+    __shared__ float Ws[NBUF * NGCF_KC * WCOLS];
+    __shared__ float ssq[BM * CW];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int rw = wave / CW, cw = wave % CW;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging roles: 4 lanes x 4 columns cover the 16 input columns of a chunk for one row
+    const int sq = tid & 3;
+    const int sr = tid >> 2;   // 0..63
+    f32x4 xle[RR], xe[RR], wreg[WN];
+
+    auto load_chunk = [&](int chunk) {       // global -> registers
+        const int c0 = chunk * NGCF_DC + sq * 4;
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
+            const int r = sr + rr * 64;
+            float le[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+            const int64_t grow = row0 + r;
+            if (r < BM && grow < n_rows) {
+                if (ALIGNED && c0 + 4 <= d_in) {
+                    const float4 a = *reinterpret_cast<const float4 *>(LE + grow * ldLE + c0);
+                    const float4 b = *reinterpret_cast<const float4 *>(Es + grow * ldE + c0);
+                    le[0] = a.x; le[1] = a.y; le[2] = a.z; le[3] = a.w;
+                    e[0] = b.x; e[1] = b.y; e[2] = b.z; e[3] = b.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < d_in) {
+                            le[q] = LE[grow * ldLE + c0 + q];
+                            e[q] = Es[grow * ldE + c0 + q];
+                        }
+                }
+            }
+            xle[rr] = f32x4{le[0], le[1], le[2], le[3]};
+            xe[rr] = f32x4{e[0], e[1], e[2], e[3]};
+        }
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
+#pragma unroll
+        for (int i = 0; i < WN; ++i) wreg[i] = src[tid + i * 256];
+    };
+    auto store_chunk = [&](int buf) {        // registers -> LDS: (LE + E) feeds W1, (LE * E) feeds W2
+        float *X = Xs + buf * (BM * XLD);
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
+            const int r = sr + rr * 64;
+            if (r < BM) {
+                const f32x4 a = xle[rr], b = xe[rr];
+                *reinterpret_cast<f32x4 *>(X + r * XLD + sq * 4) = a + b;
+                *reinterpret_cast<f32x4 *>(X + r * XLD + NGCF_DC + sq * 4) = a * b;
+            }
+        }
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Ws + buf * (NGCF_KC * WCOLS));
+#pragma unroll
+        for (int i = 0; i < WN; ++i) dst[tid + i * 256] = wreg[i];
+    };
+    auto compute_chunk = [&](int buf) {      // 32 k-values: 4 blocks of (one b128 A read, 4 x NT-wide B reads, 4*NT MFMAs)
+        const float *X = Xs + buf * (BM * XLD) + (rw * 32 + li) * XLD + lh * 4;
+        const float *W = Ws + buf * (NGCF_KC * WCOLS) + cw * (32 * NT) + li * NT;
+#pragma unroll
+        for (int kb = 0; kb < NGCF_KC / 8; ++kb) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(X + kb * 8);
+#define NGCF_KSTEP(sx, aval)                                                                                   \
+    {                                                                                                          \
+        const float *wk = W + (kb * 8 + lh * 4 + sx) * WCOLS;                                                  \
+        float bv[NT];                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) bv[t] = wk[t];                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                         \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[t], acc[t], 0, 0, 0);                       \
+    }
+            NGCF_KSTEP(0, a4.x) NGCF_KSTEP(1, a4.y) NGCF_KSTEP(2, a4.z) NGCF_KSTEP(3, a4.w)
+#undef NGCF_KSTEP
+        }
+    };
+
+    if (DB) {
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const bool more = chunk + 1 < n_chunks;
+            if (more) load_chunk(chunk + 1);        // global loads fly under the MFMAs
+            compute_chunk(chunk & 1);
+            if (more) store_chunk((chunk + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            load_chunk(chunk);
+            store_chunk(0);
+            __syncthreads();
+            compute_chunk(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, LeakyReLU, dropout, row sum of squares
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    float rowss[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = (cw * NT + t) * 32 + li;
+        const float bz = bias2[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + bz;
+            v = v >= 0.f ? v : leaky * v;
+            if (drop_p > 0.f) {
+                const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                v = h < drop_thr ? 0.f : v * keep_scale;
+            }
+            acc[t][r] = v;
+            rowss[r] = fmaf(v, v, rowss[r]);
+        }
+    }
+    // reduce over the 32 lanes that share a row (lanes li = 0..31 within each half)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = rowss[r];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        rowss[r] = s;
+    }
+    if (CW > 1) {
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ssq[lr * CW + cw] = rowss[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < CW; ++q) s += ssq[lr * CW + q];
+            rowss[r] = s;
+        }
+    }
+    // ---- stores: carry (un-normalised, feeds the next layer) and the normalised all_E block
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= n_rows) continue;
+        const float nrm = fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
+        const float inv = 1.f / nrm;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = (cw * NT + t) * 32 + li;
+            if (col < d_out) {
+                const float v = acc[t][r];
+                if (carry) carry[grow * ldc + col] = v;
+                norm[grow * ldn + col] = v * inv;
+            }
+        }
+    }
+}
+
+static int dense_dop(int d_out)
+{
+    if (d_out <= 32) return 32;
+    if (d_out <= 64) return 64;
+    if (d_out <= 96) return 96;
+    if (d_out <= 128) return 128;
+    if (d_out <= 256) return 256;
+    if (d_out <= 512) return 512;
+    return -1;
+}
+
+extern "C" int64_t ngcf_dense_workspace_bytes(int d_in, int d_out)
+{
+    const int dop = dense_dop(d_out);
+    if (dop < 0 || d_in <= 0) return -1;
+    const int64_t n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
+    return align_up((n_chunks * NGCF_KC * dop + dop) * (int64_t)sizeof(float), 256) + 256;
+}
+
+template <int RW, int CW, int NT>
+static int launch_dense(bool al, int64_t n_rows, const float *LE, int64_t ldLE, const float *Es, int64_t ldE, int d_in,
+                        int d_out, const float *Wt, const float *bias2, int n_chunks, float leaky, float drop_p,
+                        uint64_t seed, float *carry, int64_t ldc, float *norm, int64_t ldn, hipStream_t stream)
+{
+    const int64_t blocks = (n_rows + 32 * RW - 1) / (32 * RW);
+    if (blocks == 0) return NGCF_OK;
+    if (al)
+        layer_dense_kernel<RW, CW, NT, true><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+    else
+        layer_dense_kernel<RW, CW, NT, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *Es, int64_t ldEs, int64_t n_rows,
+                                    int d_in, const float *W1, const float *b1, const float *W2, const float *b2,
+                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, float *carry,
+                                    int64_t ldc, float *norm, int64_t ldn, void *workspace, int64_t workspace_bytes,
+                                    void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!LE || !Es || !W1 || !b1 || !W2 || !b2 || !norm) return fail(NGCF_ERR_ARG, "layer_dense: null argument");
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0) return fail(NGCF_ERR_ARG, "layer_dense: bad sizes");
+    const int dop = dense_dop(d_out);
+    if (dop < 0) return fail(NGCF_ERR_ARG, "layer_dense: d_out=%d > 512 is not supported", d_out);
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "layer_dense: drop_p=%f not in [0,1)", drop_p);
+    if (ldLE < d_in || ldEs < d_in || ldn < d_out || (carry && ldc < d_out))
+        return fail(NGCF_ERR_ARG, "layer_dense: leading dimension too small");
+    const int64_t need = ngcf_dense_workspace_bytes(d_in, d_out);
+    if (!workspace || workspace_bytes < need)
+        return fail(NGCF_ERR_WORKSPACE, "layer_dense: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    const int n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
+    float *Wt = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    float *bias2 = Wt + (int64_t)n_chunks * NGCF_KC * dop;
+    pack_weights_kernel<<<64, 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, dop <= 128 ? dop / 32 : 4, Wt, bias2);
+    LAUNCH_CHECK();
+    const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
+#define NGCF_DENSE(RW, CW, NT) \
+    return launch_dense<RW, CW, NT>(al, n_rows, LE, ldLE, Es, ldEs, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, \
+                                    drop_seed, carry, ldc, norm, ldn, stream)
+    switch (dop) {
+    case 32: NGCF_DENSE(4, 1, 1);
+    case 64: NGCF_DENSE(4, 1, 2);
+    case 96: NGCF_DENSE(4, 1, 3);
+    case 128: NGCF_DENSE(4, 1, 4);
+    case 256: NGCF_DENSE(2, 2, 4);
+    default: NGCF_DENSE(1, 4, 4);
+    }
+#undef NGCF_DENSE
+}
+
+extern "C" int64_t ngcf_layer_workspace_bytes(const ngcf_csr_t *c, int d_in, int d_out)
+{
+    if (!c) return -1;
+    const int64_t a = ngcf_spmm_workspace_bytes(c, d_in);
+    const int64_t b = ngcf_dense_workspace_bytes(d_in, d_out);
+    if (a < 0 || b < 0) return -1;
+    const int64_t le = align_up(c->n_rows * align_up(d_in, 4) * (int64_t)sizeof(float), 256);
+    return a + b + le + 256;
+}
+
+extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_t ldEg, const float *Es, int64_t ldEs,
+                                    int d_in, const float *W1, const float *b1, const float *W2, const float *b2,
+                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, float *carry,
+                                    int64_t ldc, float *norm, int64_t ldn, void *workspace, int64_t workspace_bytes,
+                                    void *stream)
+{
+    if (!c) return fail(NGCF_ERR_ARG, "layer_fused: null csr");
+    const int64_t need = ngcf_layer_workspace_bytes(c, d_in, d_out);
+    if (need < 0) return fail(NGCF_ERR_ARG, "layer_fused: unsupported widths d_in=%d d_out=%d", d_in, d_out);
+    if (!workspace || workspace_bytes < need)
+        return fail(NGCF_ERR_WORKSPACE, "layer_fused: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    char *ws = reinterpret_cast<char *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    const int64_t ldLE = align_up(d_in, 4);
+    float *LE = reinterpret_cast<float *>(ws);
+    ws += align_up(c->n_rows * ldLE * (int64_t)sizeof(float), 256);
+    const int64_t spmm_ws = ngcf_spmm_workspace_bytes(c, d_in);
+    void *ws_spmm = ws;
+    ws += spmm_ws;
+    const int64_t dense_ws = ngcf_dense_workspace_bytes(d_in, d_out);
+    void *ws_dense = ws;
+    int rc = ngcf_spmm_csr_f32(c, Eg, ldEg, d_in, LE, ldLE, ws_spmm, spmm_ws, stream);
+    if (rc != NGCF_OK) return rc;
+    return ngcf_layer_dense_f32(LE, ldLE, Es, ldEs, c->n_rows, d_in, W1, b1, W2, b2, d_out, leaky, drop_p, drop_seed,
+                                carry, ldc, norm, ldn, ws_dense, dense_ws, stream);
+}
+

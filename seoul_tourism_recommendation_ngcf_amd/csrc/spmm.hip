@@ -1,0 +1,242 @@
+// spmm.hip - row-wise CSR SpMM kernels (plain + d-sliced), dispatch, workspace sizing, launch timing.
+#include "spmm_device.h"
+
+// One launch covers the whole product: the first `seg_blocks` workgroups take the segments of the cut
+// rows (the longest units, so they start first; partial sums go to the workspace [n_seg][dp]), the rest
+// take one uncut row per wave and write it directly.  Cut rows are finished by spmm_fixup_kernel.
+template <int VEC, int LPR, int CH, int U>
+__global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ colidx,
+                                                   const float *__restrict__ vals, int64_t row_begin,
+                                                   int64_t n_rows, const int32_t *__restrict__ seg_row,
+                                                   const int64_t *__restrict__ seg_begin, int64_t n_seg,
+                                                   int64_t seg_blocks, int seg_len,
+                                                   const float *__restrict__ E, int64_t ldE, int d,
+                                                   float *__restrict__ out, int64_t ldo,
+                                                   float *__restrict__ partial, int dp, EdgeDrop dr)
+{
+    using V = typename VecT<VEC>::type;
+    const int wave = threadIdx.x >> 6;
+    int64_t begin, end;
+    float *dst;
+    if ((int64_t)blockIdx.x < seg_blocks) {
+        const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+        if (s >= n_seg) return;
+        begin = seg_begin[s];
+        const int64_t row_end = rowptr[seg_row[s] + 1];
+        end = begin + seg_len < row_end ? begin + seg_len : row_end;
+        dst = partial + s * (int64_t)dp;
+    } else {
+        const int64_t row = row_begin + ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
+        if (row >= n_rows) return;
+        begin = rowptr[row];
+        end = rowptr[row + 1];
+        if (end - begin > seg_len) return;   // cut row: produced from its segments
+        dst = out + row * ldo;
+    }
+    V acc[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) acc[ch] = vzero<VEC>();
+    spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc, dr);
+    spmm_store<VEC, LPR, CH>(acc, dst, d);
+}
+
+// Rows [row_begin, row_end) in slices of 32 floats, slice-major: every CU works on the same 128-B slice of the
+// gathered table at a time, so for a table of a few hundred thousand rows the hot rows of that slice stay in L2.
+template <int U>
+__global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ colidx,
+                                                          const float *__restrict__ vals, int64_t row_begin,
+                                                          int64_t row_end, int64_t row_blocks, int seg_len,
+                                                          const float *__restrict__ E, int64_t ldE,
+                                                          float *__restrict__ out, int64_t ldo, EdgeDrop dr)
+{
+    const int64_t slice = blockIdx.x / row_blocks;
+    const int64_t row = row_begin + ((int64_t)blockIdx.x % row_blocks) * 4 + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    const int64_t begin = rowptr[row], end = rowptr[row + 1];
+    if (end - begin > seg_len) return;   // cut row: produced from its segments
+    float4 acc[1];
+    acc[0] = vzero4();
+    spmm_accumulate<4, 8, 1, U>(colidx, vals, begin, end, E + slice * 32, ldE, 32, acc, dr);
+    spmm_store<4, 8, 1>(acc, out + row * ldo + slice * 32, 32);
+}
+
+
+extern "C" int64_t ngcf_spmm_workspace_bytes(const ngcf_csr_t *c, int d)
+{
+    if (!c || d <= 0) return -1;
+    const int64_t n_part = std::max(c->n_seg, c->swept.n_partial);
+    return align_up(n_part * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optional in-library timing of the dominant kernel (bench.py's roofline figure): when enabled,
+// a hipEvent pair is recorded on the launch stream around every spmm_kernel launch.
+// ---------------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_events;   // pairs: begin, end
+static size_t g_prof_used = 0;
+
+void prof_mark(hipStream_t stream, int which)
+{
+    if (!g_prof_on) return;
+    if (g_prof_used >= g_prof_events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_prof_events.push_back(e);
+    }
+    (void)which;
+    (void)hipEventRecord(g_prof_events[g_prof_used++], stream);
+}
+
+extern "C" int ngcf_prof_enable(int on)
+{
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return NGCF_OK;
+}
+
+// Waits for the recorded events; returns the number of timed spmm launches and their summed duration.
+extern "C" int ngcf_prof_collect(int64_t *n_launches, double *total_ms)
+{
+    if (!n_launches || !total_ms) return fail(NGCF_ERR_ARG, "prof_collect: null argument");
+    double sum = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(g_prof_events[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
+        sum += ms;
+        ++n;
+    }
+    *n_launches = n;
+    *total_ms = sum;
+    g_prof_used = 0;
+    return NGCF_OK;
+}
+
+namespace {
+struct SpmmArgs {
+    const ngcf_csr *c;
+    const float *E;
+    int64_t ldE;
+    int d;
+    float *out;
+    int64_t ldo;
+    float *partial;
+    int dp;
+    hipStream_t stream;
+    EdgeDrop dr;
+};
+
+template <int VEC, int LPR, int CH, int U>
+int launch_spmm(const SpmmArgs &a)
+{
+    const ngcf_csr *c = a.c;
+    const int64_t seg_blocks = (c->n_seg + 3) / 4;
+    // d-slicing of the sliceable row groups needs 16-byte slices of 32 floats
+    const bool can_slice = VEC == 4 && a.d % 32 == 0 && a.d >= 64 && c->mode != 1 && !getenv("NGCF_NO_SLICING");
+    prof_mark(a.stream, 0);
+    bool seg_done = seg_blocks == 0;
+    for (size_t g = 0; g <= c->groups.size(); ++g) {
+        const bool last = g == c->groups.size();
+        if (last && seg_done) break;
+        if (!last && can_slice && c->groups[g].sliceable) {
+            const int64_t rb = (c->groups[g].end - c->groups[g].begin + 3) / 4;
+            const int64_t blocks = rb * (a.d / 32);
+            if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+            spmm_sliced_kernel<8><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(c->rowptr, c->colidx, c->vals, c->groups[g].begin,
+                                                                               c->groups[g].end, rb, c->seg_len, a.E, a.ldE,
+                                                                               a.out, a.ldo, a.dr);
+            LAUNCH_CHECK();
+            continue;
+        }
+        // unsliced group; the segments of the cut rows ride in front of the first such launch
+        const int64_t rbeg = last ? 0 : c->groups[g].begin, rend = last ? 0 : c->groups[g].end;
+        const int64_t sb = seg_done ? 0 : seg_blocks;
+        const int64_t blocks = sb + (rend - rbeg + 3) / 4;
+        if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+        if (blocks > 0) {
+            spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
+                c->rowptr, c->colidx, c->vals, rbeg, rend, c->seg_row, c->seg_begin, seg_done ? 0 : c->n_seg, sb, c->seg_len,
+                a.E, a.ldE, a.d, a.out, a.ldo, a.partial, a.dp, a.dr);
+            LAUNCH_CHECK();
+        }
+        seg_done = true;
+    }
+    prof_mark(a.stream, 1);
+    if (c->n_heavy > 0) {
+        const int64_t fb = (c->n_heavy + 3) / 4;
+        spmm_fixup_kernel<VEC><<<dim3((unsigned)fb), 256, 0, a.stream>>>(c->heavy_row, c->heavy_seg_ptr, c->n_heavy,
+                                                                          a.partial, a.dp, a.d, a.out, a.ldo);
+        LAUNCH_CHECK();
+    }
+    return NGCF_OK;
+}
+}  // namespace
+
+int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, void *workspace,
+                  int64_t workspace_bytes, hipStream_t stream, const EdgeDrop &dr)
+{
+    if (!c || !E || !out) return fail(NGCF_ERR_ARG, "spmm: null argument");
+    if (d <= 0 || d > 8192) return fail(NGCF_ERR_ARG, "spmm: width d=%d not in [1, 8192]", d);
+    if (ldE < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm: leading dimension smaller than d");
+    if (d > 512) {   // wider than one wave covers: column panels of 512 (Seoul's 515-wide first layer, BASELINE configs[1])
+        for (int o = 0; o < d; o += 512) {
+            const int rc = spmm_dispatch(c, E + o, ldE, std::min(512, d - o), out + o, ldo, workspace, workspace_bytes, stream, dr);
+            if (rc != NGCF_OK) return rc;
+        }
+        return NGCF_OK;
+    }
+    const int dp = (int)align_up(d, 4);
+    float *partial = nullptr;
+    if (c->n_seg > 0) {
+        const int64_t need = ngcf_spmm_workspace_bytes(c, d);
+        if (!workspace || workspace_bytes < need)
+            return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+        partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    }
+    SpmmArgs a{c, E, ldE, d, out, ldo, partial, dp, stream, dr};
+    const bool vec = (d % 4 == 0) && (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
+    const ngcf_csr::Swept &w = c->swept;
+    if (vec && d % 64 == 0 && w.n_owners > 0 && c->mode == 2 && dr.n == 0) {
+        if (w.n_partial > 0 && !partial) {
+            const int64_t need = ngcf_spmm_workspace_bytes(c, d);
+            if (!workspace || workspace_bytes < need)
+                return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+            partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+        }
+        return launch_swept(c, E, ldE, d, out, ldo, partial, dp, stream);
+    }
+    if (vec) {
+        const int nq = d / 4;
+        if (nq <= 8) return launch_spmm<4, 8, 1, 4>(a);
+        if (nq <= 16) return launch_spmm<4, 16, 1, 8>(a);
+        if (nq <= 32) return launch_spmm<4, 32, 1, 8>(a);
+        if (nq <= 64) return launch_spmm<4, 64, 1, 8>(a);
+        return launch_spmm<4, 64, 2, 4>(a);
+    }
+    if (d <= 64) return launch_spmm<1, 64, 1, 8>(a);
+    if (d <= 128) return launch_spmm<1, 64, 2, 4>(a);
+    if (d <= 256) return launch_spmm<1, 64, 4, 2>(a);
+    return launch_spmm<1, 64, 8, 1>(a);
+}
+
+extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
+                                 void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return spmm_dispatch(c, E, ldE, d, LE, ldLE, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
+                                         float drop_p, const uint64_t *seeds, int n_seeds, const int64_t *eid,
+                                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_dropout: 0..4 seeds expected");
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "spmm_dropout: drop_p=%f not in [0,1)", drop_p);
+    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, eid};
+    for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
+    return spmm_dispatch(c, E, ldE, d, LE, ldLE, workspace, workspace_bytes, (hipStream_t)stream, dr);
+}
+

@@ -1,0 +1,138 @@
+// Device-side building blocks of the row-wise SpMM (shared by spmm.hip and tools/spmm_lab.hip).
+#ifndef NGCF_SPMM_DEVICE_H
+#define NGCF_SPMM_DEVICE_H
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// SpMM  LE = L.E   (NGCF.py:130)
+//
+// One wave owns one row (or one <= seg_len-entry segment of a long row).  The wave first reads up
+// to 64 (col, val) pairs with one coalesced load per lane, then walks them: LPR lanes cover one
+// gathered row of E with one 16-byte load each (VEC = 4), so G = 64/LPR neighbour rows are fetched
+// per wave-instruction and U such instructions are kept in flight.  The G lane groups keep
+// private partial sums that are combined with DPP/bpermute shuffles at the end.
+// VEC = 1 is the any-width / any-alignment form (Seoul's d = 65).
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPR, int CH, int U>
+__device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                       int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
+                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr})
+{
+    using V = typename VecT<VEC>::type;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPR;
+    const int l = lane % LPR;
+    // column offset of each chunk this lane covers; lanes past the row width read column 0 and
+    // are never written back
+    int coff[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int o = (l + ch * LPR) * VEC;
+        coff[ch] = o < d ? o : 0;
+    }
+    for (int64_t base = begin; base < end; base += 64) {
+        int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+        int c = 0;       // column 0 is always a valid row of E: padding slots read it, masked below
+        float v = 0.f;
+        if (lane < cnt) {
+            c = colidx[base + lane];
+            v = vals[base + lane];
+        }
+        if (dr.n > 0) {
+            // drop entries, then compact the survivors to the low lanes (dropped ones go to the top, unused)
+            bool keep = lane < cnt;
+            if (keep) {
+                const uint64_t e = (uint64_t)(dr.eid ? dr.eid[base + lane] : base + lane) * 0x9E3779B97F4A7C15ULL;
+                for (int q = 0; q < dr.n; ++q) keep = keep && mix32(dr.seed[q] ^ e) >= dr.thr;
+            }
+            const unsigned long long m = __ballot(keep);
+            const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+            const int dst = keep ? __popcll(m & lt) : 63 - __popcll(~m & lt);
+            c = __builtin_amdgcn_ds_permute(dst << 2, c);
+            v = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v)));
+            cnt = __popcll(m);
+        }
+        int j = 0;
+        for (; j + G * U <= cnt; j += G * U) {          // full batches: every slot is a real entry
+            V x[U][CH];
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * G + g;
+                const int cc = __shfl(c, idx);
+                vv[u] = __shfl(v, idx);
+                const float *src = E + (int64_t)cc * ldE;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) acc[ch] = vfma(vv[u], x[u][ch], acc[ch]);
+        }
+        if (j < cnt) {                                   // tail batch: slots past cnt are masked
+            V x[U][CH];
+            float vv[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * G + g;
+                ok[u] = idx < cnt;
+                const int cc = __shfl(c, idx & 63);
+                vv[u] = __shfl(v, idx & 63);
+                const float *src = E + (int64_t)cc * ldE;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) acc[ch] = vsel(ok[u], vfma(vv[u], x[u][ch], acc[ch]), acc[ch]);
+        }
+    }
+    // combine the G lane groups
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) acc[ch] = vadd(acc[ch], vshfl_xor(acc[ch], off));
+}
+
+template <int VEC, int LPR, int CH>
+__device__ inline void spmm_store(typename VecT<VEC>::type (&acc)[CH], float *__restrict__ dst, int d)
+{
+    using V = typename VecT<VEC>::type;
+    const int lane = threadIdx.x & 63;
+    if (lane >= LPR) return;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int o = (lane + ch * LPR) * VEC;
+        if (o < d) *reinterpret_cast<V *>(dst + o) = acc[ch];
+    }
+}
+
+
+// cut rows: add their segments' partial sums in segment order (fixed order, no atomics)
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restrict__ heavy_row,
+                                                         const int64_t *__restrict__ heavy_seg_ptr,
+                                                         int64_t n_heavy, const float *__restrict__ partial,
+                                                         int dp, int d, float *__restrict__ out, int64_t ldo)
+{
+    using V = typename VecT<VEC>::type;
+    const int64_t h = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n_heavy) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = heavy_seg_ptr[h], s1 = heavy_seg_ptr[h + 1];
+    float *dst = out + (int64_t)heavy_row[h] * ldo;
+    for (int o = lane * VEC; o < d; o += 64 * VEC) {
+        V acc = vzero<VEC>();
+        for (int64_t s = s0; s < s1; ++s) acc = vadd(acc, *reinterpret_cast<const V *>(partial + s * (int64_t)dp + o));
+        *reinterpret_cast<V *>(dst + o) = acc;
+    }
+}
+
+
+
+#endif  // NGCF_SPMM_DEVICE_H

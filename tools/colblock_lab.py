@@ -18,7 +18,7 @@ E = torch.randn((N, d), device=dev)
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ir, ic = rows[nu:], coo["cols"][nu:]
-for nblk in (1, 2, 3, 4, 6, 8, 16):
+for nblk in (1, 16, 32, 64, 128):
     brows = (U + nblk - 1) // nblk
     key = ir * nblk + ic // brows                      # (row, block) id, non-decreasing within a row
     change = torch.ones_like(key, dtype=torch.bool)

@@ -1,6 +1,8 @@
 // Experimental SpMM variants (NOT product code): d-slicing and unroll depth on top of the product's
 // spmm_accumulate.  One wave per work unit (row or row segment); units come from tools/spmm_lab.py.
-#include "../seoul_tourism_recommendation_ngcf_amd/csrc/ngcf_hip.hip"
+#include "../seoul_tourism_recommendation_ngcf_amd/csrc/spmm_device.h"
+
+void prof_mark(hipStream_t, int) {}   // the lab does not time through the library
 
 // LPR lanes cover one slice of S = 4*LPR floats of a gathered row; G = 64/LPR rows per wave-instruction.
 template <int LPR, int U>
@@ -89,5 +91,45 @@ extern "C" int lab_launch_acc(int variant, const int64_t *ubeg, const int64_t *u
     case 6: GO2(32, 4); break;
     default: return 1;
     }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// mixed launch: every workgroup is either a d-sliced block of 4 user rows or an unsliced block of 4 item units;
+// `sched[blockIdx]` >= 0: user block (slice-major index), < 0: item block -1-index.  Does interleaving the
+// L2-friendly half with the fabric-bound half overlap them?
+__global__ __launch_bounds__(256) void lab_mixed(const int32_t *__restrict__ sched, const int64_t *__restrict__ rowptr,
+                                                 int64_t n_user, int64_t user_row_blocks, const int64_t *__restrict__ ubeg,
+                                                 const int64_t *__restrict__ uend, const int64_t *__restrict__ udst,
+                                                 int64_t n_units, const int32_t *__restrict__ colidx,
+                                                 const float *__restrict__ vals, const float *__restrict__ E, int64_t ldE,
+                                                 float *__restrict__ out, int64_t ldo)
+{
+    const int32_t sc = sched[blockIdx.x];
+    const int wave = threadIdx.x >> 6;
+    if (sc >= 0) {
+        const int64_t slice = sc / user_row_blocks;
+        const int64_t row = ((int64_t)sc % user_row_blocks) * 4 + wave;
+        if (row >= n_user) return;
+        float4 acc[1];
+        acc[0] = vzero4();
+        spmm_accumulate<4, 8, 1, 8>(colidx, vals, rowptr[row], rowptr[row + 1], E + slice * 32, ldE, 32, acc);
+        spmm_store<4, 8, 1>(acc, out + row * ldo + slice * 32, 32);
+    } else {
+        const int64_t unit = (int64_t)(-1 - sc) * 4 + wave;
+        if (unit >= n_units) return;
+        float4 acc[1];
+        acc[0] = vzero4();
+        spmm_accumulate<4, 32, 1, 8>(colidx, vals, ubeg[unit], uend[unit], E, ldE, 128, acc);
+        spmm_store<4, 32, 1>(acc, out + udst[unit] * ldo, 128);
+    }
+}
+
+extern "C" int lab_launch_mixed(const int32_t *sched, int64_t n_blocks, const int64_t *rowptr, int64_t n_user,
+                                int64_t user_row_blocks, const int64_t *ubeg, const int64_t *uend, const int64_t *udst,
+                                int64_t n_units, const int32_t *colidx, const float *vals, const float *E, int64_t ldE,
+                                float *out, int64_t ldo, void *stream_)
+{
+    lab_mixed<<<dim3((unsigned)n_blocks), 256, 0, (hipStream_t)stream_>>>(sched, rowptr, n_user, user_row_blocks, ubeg, uend, udst,
+                                                                          n_units, colidx, vals, E, ldE, out, ldo);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
