@@ -140,12 +140,12 @@ def _cpu_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_exchange_plumbing_on_gloo_cpu():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_exchange_plumbing_on_gloo_cpu(world):
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_cpu_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-        assert dict(ret) == {0: 1, 1: 1}
+        assert dict(ret) == {r: 1 for r in range(world)}
 
 
 def test_layout_and_bounds_single_process():
@@ -206,10 +206,9 @@ def _gpu_worker(rank, world, port, mode, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bipartite", "allgather"])
-def test_sharded_propagation_two_ranks_one_gpu(mode):
-    world = 2
+@pytest.mark.parametrize("mode,world", [("bipartite", 2), ("allgather", 2), ("bipartite", 3), ("allgather", 3)])
+def test_sharded_propagation_ranks_share_one_gpu(mode, world):
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_gpu_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
-        assert dict(ret) == {0: True, 1: True}
+        assert dict(ret) == {r: True for r in range(world)}
