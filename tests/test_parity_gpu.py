@@ -506,3 +506,39 @@ def test_seoul_standin_forward_matches_oracle(embed, layers, dev):
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=ATOL, rtol=RTOL)
     assert torch.equal(model.user_embedding.weight.detach().cpu(), uw)
     assert n.numel() == 0 and torch.equal(u.cpu(), got[:U][batch["u_id"]]) and torch.equal(p.cpu(), got[U:][batch["pos_item"]])
+
+
+# --------------------------------------------------------------------------------------------
+# edge cases of the module surface
+# --------------------------------------------------------------------------------------------
+def test_forward_edge_cases_empty_batch_single_layer_and_device_move(dev):
+    pkg = _pkg()
+    coo = pkg.graphs.synthetic_bipartite(400, 30, 4000, seed=6, device="cpu")       # lap_list kept on the CPU
+    lap = pkg.graphs.to_sparse_coo(coo)
+    num_dict = {"user": 400, "item": 30, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(3)
+    model = pkg.NGCF(65, [64], 0.3, [0.1], 1.0, [lap], num_dict, 4, torch.device("cpu"))    # one layer
+    model = model.to(dev).eval()
+    empty = torch.empty(0, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        u, p, n = model(year=torch.tensor([18], device=dev), u_id=empty, age=empty, sex=empty, month=empty, day=empty,
+                        dow=empty, pos_item=empty, neg_item=torch.empty(0), node_flag=False)
+    assert u.shape == (0, 129) and p.shape == (0, 129) and n.numel() == 0
+    assert model.all_users_emb.shape == (400, 129) and model.all_items_emb.shape == (30, 129)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = orc.propagate_torch(lap, sd["user_embedding.weight"], sd["item_embedding.weight"], [sd["w1_list.0.weight"]],
+                               [sd["w1_list.0.bias"]], [sd["w2_list.0.weight"]], [sd["w2_list.0.bias"]])
+    got = torch.cat((model.all_users_emb, model.all_items_emb), 0).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=ATOL, rtol=RTOL)
+    # widths the dense kernel does not cover fail loudly (no silent fallback)
+    wide = pkg.NGCF(65, [600], None, None, 1.0, [lap], num_dict, 4, dev).to(dev).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="512"):
+        wide.propagate(0)
+    # moving the module to the CPU makes forward raise again (no fallback), moving back works
+    model.cpu()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model.propagate(0)
+    model.to(dev)
+    with torch.no_grad():
+        again = model.propagate(0)
+    assert torch.equal(again.cpu(), got)
