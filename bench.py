@@ -201,7 +201,7 @@ def main():
                    "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
                    "d": d0, "n_layers": n_layer, "batch": args.batch,
                    "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, exchange={args.exchange}"},
-        "roofline": {"bound": "hbm", "kernel": "spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "spmm_kernel + spmm_sliced_kernel (one L.E product)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
                      "mean_launch_ms": mean_ms,
@@ -209,7 +209,7 @@ def main():
         "loss": float(loss),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(coo, model, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(coo, model, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
