@@ -99,7 +99,7 @@ struct ngcf_csr {
 };
 
 
-static const int32_t kDefaultSegLen = 512;
+static const int32_t kDefaultSegLen = 2048;   // measured on C3: 512 -> 20.9 ms/step, 2048 -> 20.6, 4096 -> 20.5
 
 void free_swept(ngcf_csr *c);                                  // spmm_swept.hip
 int build_swept_plan(ngcf_csr *c, hipStream_t stream);         // spmm_swept.hip
