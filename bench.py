@@ -35,6 +35,9 @@ WORKLOADS = {
     "c3": (1_000_000, 100_000, 50_000_000, 128, (128, 128, 128), 2603),
     "c5": (10_000_000, 1_000_000, 500_000_000, 256, (256, 256, 256), 2605),
     "small": (100_000, 10_000, 2_000_000, 128, (128, 128, 128), 2603),
+    # BASELINE.json configs[0..1]: Seoul-shaped stand-in graph, full nn.Module forward incl. injection
+    "c1": (5840, 100, 0, 65, (64, 64), 1801),
+    "c2": (5840, 100, 0, 515, (512, 512), 1801),
 }
 
 
@@ -50,6 +53,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-items", action="store_true", help="secondary line: no popularity skew")
     return ap.parse_args()
+
+
+def host_cores():
+    """Host threads for the CPU baseline: this process's share of the node (a 1-GPU box gets 16 cores; the affinity
+    mask may list every CPU of the node, and hundreds of threads only thrash on these matrix sizes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))
 
 
 def spmm_model_a_bytes(nnz, n_rows, n_cols, d):
@@ -75,6 +85,29 @@ def cpu_baseline(coo, model, n_threads):
     return {"value": coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
             "sample": f"1 of 3 layers (SpMM + 3 Linear + LeakyReLU + normalize + cat) of the same graph, "
                       f"nnz(L)={coo['nnz']}, d=128, torch {torch.__version__} CPU, {dt:.1f} s, single run",
+            "seconds": dt}
+
+
+def cpu_baseline_full(coo, model, n_threads):
+    """Seoul-sized workloads: the whole propagation (all layers) of the CPU oracle, median of 5 runs."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ngcf_oracle as orc
+    N = coo["n_user"] + coo["n_item"]
+    L = torch.sparse_coo_tensor(torch.stack([coo["rows"], coo["cols"]]).cpu(), coo["vals"].cpu(), (N, N))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    n_layer = model.n_layer
+    w = [[sd[f"{nm}.{k}.{t}"] for k in range(n_layer)] for nm, t in (("w1_list", "weight"), ("w1_list", "bias"),
+                                                                     ("w2_list", "weight"), ("w2_list", "bias"))]
+    torch.set_num_threads(n_threads)
+    times = []
+    with torch.no_grad():
+        for _ in range(6):
+            t0 = time.perf_counter()
+            orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], *w)
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[2]
+    return {"value": n_layer * coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
+            "sample": f"whole {n_layer}-layer propagation, median of 5 after 1 warm-up, torch {torch.__version__} CPU, {dt * 1e3:.1f} ms",
             "seconds": dt}
 
 
@@ -106,8 +139,14 @@ def main():
     lib = _lib.load()
 
     n_user, n_item, n_inter, d0, layers, seed = WORKLOADS[args.workload]
-    coo = pkg.graphs.synthetic_bipartite(n_user, n_item, n_inter, seed=seed, device=dev,
-                                         item_skew=not args.uniform_items)
+    seoul = args.workload in ("c1", "c2")
+    if seoul:
+        if world != 1:
+            raise SystemExit("the Seoul-shaped workloads are single-GPU configurations")
+        coo = pkg.graphs.seoul_standin(dev, seed=seed, n_user=n_user, n_item=n_item)[0]
+    else:
+        coo = pkg.graphs.synthetic_bipartite(n_user, n_item, n_inter, seed=seed, device=dev,
+                                             item_skew=not args.uniform_items)
     nnz, N = coo["nnz"], n_user + n_item
     num_dict = {"user": n_user, "item": n_item, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
     torch.manual_seed(seed)                                   # same parameters on every rank
@@ -121,7 +160,18 @@ def main():
     neg = torch.randint(0, n_item, (args.batch,), generator=g).to(dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    if world == 1:
+    if seoul:
+        csr = model.laplacian_csr(0)
+        local_nnz = csr.nnz
+        spmm_shapes = [(csr.nnz, csr.n_rows, csr.n_cols)]
+        feats = {k: torch.randint(0, c, (args.batch,), generator=g).to(dev)
+                 for k, c in (("age", 76), ("sex", 2), ("month", 13), ("day", 32), ("dow", 7))}
+        year = torch.full((args.batch,), 18, device=dev)
+
+        def step():                                   # the whole NGCF.forward incl. the feature injection, then BPR
+            u, p, n = model(year=year, u_id=u_id, pos_item=pos, neg_item=neg, node_flag=False, **feats)
+            return crit(u, p, n)
+    elif world == 1:
         csr = model.laplacian_csr(0)
         if args.seg_len:
             csr.plan(args.seg_len)
@@ -195,7 +245,7 @@ def main():
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: synthetic bipartite {n_user} users x {n_item} items, "
+        "config": {"workload": f"{args.workload}: {'Seoul-shaped stand-in' if seoul else 'synthetic bipartite'} {n_user} users x {n_item} items, "
                                f"{coo['interactions']} interactions, nnz(L)={nnz}, d0={d0}, layers={list(layers)}, "
                                f"batch={args.batch}, seed={seed}" + (", uniform items" if args.uniform_items else ""),
                    "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
@@ -208,8 +258,12 @@ def main():
                      "gather_bytes_per_launch": local_nnz / max(len(spmm_shapes), 1) * d0 * 4 if world > 1 else nnz * d0 * 4},
         "loss": float(loss),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(coo, model, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if seoul:
+        out["roofline"]["note"] = "working set is cache-resident at this size: the HBM fraction is not meaningful (SURVEY 8d)"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and seoul:
+        out["cpu_baseline"] = cpu_baseline_full(coo, model, host_cores())
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(coo, model, host_cores())
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
