@@ -542,3 +542,49 @@ def test_forward_edge_cases_empty_batch_single_layer_and_device_move(dev):
     with torch.no_grad():
         again = model.propagate(0)
     assert torch.equal(again.cpu(), got)
+
+
+def test_full_size_c3_properties(dev):
+    """BASELINE.json configs[2] at FULL size (1 M x 100 K, ~100 M stored entries, d=128): size-independent
+    properties - linearity, symmetry of L, fp64 spot rows (incl. the heaviest item row), unit-norm blocks."""
+    pkg = _pkg()
+    eng = pkg.engine
+    U, I = 1_000_000, 100_000
+    coo = pkg.graphs.synthetic_bipartite(U, I, 50_000_000, seed=2603, device=dev)
+    N = U + I
+    assert coo["nnz"] == 2 * coo["interactions"] and coo["nnz"] > 99_000_000
+    num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(2603)
+    model = pkg.NGCF(128, [128, 128, 128], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 1024, dev).to(dev).eval()
+    csr = model.laplacian_csr(0)
+    assert csr.nnz == coo["nnz"] and csr.n_segments > 0
+    g = torch.Generator(device=dev).manual_seed(9)
+    X = torch.randn((N, 128), generator=g, device=dev)
+    Y = torch.randn((N, 128), generator=g, device=dev)
+    LX, LY = eng.spmm(csr, X), eng.spmm(csr, Y)
+    LZ = eng.spmm(csr, 3.0 * X + 0.25 * Y)
+    scale = float(LX.abs().max())
+    assert float((LZ - (3.0 * LX + 0.25 * LY)).abs().max()) <= 2e-5 * max(scale, 1.0)
+    a, b = float((Y.double() * LX.double()).sum()), float((LY.double() * X.double()).sum())
+    assert abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1.0) + 1e-2
+    rows = torch.cat([torch.randint(0, N, (24,), device=dev), torch.tensor([U, U + 1, 0], device=dev)])
+    rp = torch.searchsorted(coo["rows"], torch.stack([rows, rows + 1]))
+    for r, (lo, hi) in zip(rows.tolist(), rp.T.tolist()):
+        want = (coo["vals"][lo:hi].double()[:, None] * X[coo["cols"][lo:hi]].double()).sum(0)
+        np.testing.assert_allclose(LX[r].cpu().numpy(), want.cpu().numpy(), atol=ATOL, rtol=RTOL)
+    with torch.no_grad():
+        all_E = model.propagate(0)
+    assert all_E.shape == (N, 512) and bool(torch.isfinite(all_E).all())
+    assert torch.equal(all_E[:U, :128], model.user_embedding.weight.detach())          # block 0 is E0, bit for bit
+    for k in range(3):
+        nrm = all_E[:, 128 * (k + 1):128 * (k + 2)].norm(dim=1)
+        assert float((nrm - 1).abs().max()) < 1e-5
+    # layer 1 of a sample of rows against fp64 from the definition (NGCF.py:130-144)
+    sd = {k_: v.detach() for k_, v in model.state_dict().items()}
+    E0 = all_E[:, :128].double()
+    W1, b1, W2, b2 = (sd[f"{n_}.0.{t}"].double() for n_, t in (("w1_list", "weight"), ("w1_list", "bias"), ("w2_list", "weight"), ("w2_list", "bias")))
+    for r, (lo, hi) in list(zip(rows.tolist(), rp.T.tolist()))[-6:]:
+        le = (coo["vals"][lo:hi].double()[:, None] * E0[coo["cols"][lo:hi]]).sum(0)
+        m = (le + E0[r]) @ W1.T + 2 * b1 + (le * E0[r]) @ W2.T + b2
+        m = torch.where(m >= 0, m, 0.2 * m)
+        np.testing.assert_allclose(all_E[r, 128:256].cpu().numpy(), (m / m.norm()).cpu().numpy(), atol=ATOL, rtol=RTOL)
