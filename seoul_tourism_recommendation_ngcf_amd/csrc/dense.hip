@@ -40,7 +40,7 @@ __global__ void pack_weights_kernel(const float *__restrict__ W1, const float *_
         bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
 }
 
-template <int RW, int CW, int NT, bool ALIGNED>
+template <int RW, int CW, int NT, bool ALIGNED, bool FAST>
 __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restrict__ LE, int64_t ldLE,
                                                           const float *__restrict__ Es, int64_t ldE, int64_t n_rows,
                                                           int d_in, int d_out, const float *__restrict__ Wt,
@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
 
     auto load_chunk = [&](int chunk) {       // global -> registers
         const int c0 = chunk * NGCF_DC + sq * 4;
+        if constexpr (FAST) {   // every chunk is a full, 16-byte aligned float4 per lane
+            // branch-free: rows past the end re-read the last row (never stored), so the loads stay in flight
+            // under the MFMAs of the current chunk instead of being waited for inside a conditional
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr) {
+                int64_t grow = row0 + (sr + rr * 64) % BM;
+                grow = grow < n_rows ? grow : n_rows - 1;
+                xle[rr] = *reinterpret_cast<const f32x4 *>(LE + grow * ldLE + c0);
+                xe[rr] = *reinterpret_cast<const f32x4 *>(Es + grow * ldE + c0);
+            }
+            const f32x4 *srcw = reinterpret_cast<const f32x4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
+#pragma unroll
+            for (int i = 0; i < WN; ++i) wreg[i] = srcw[tid + i * 256];
+            return;
+        }
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) {
             const int r = sr + rr * 64;
@@ -258,11 +273,14 @@ static int launch_dense(bool al, int64_t n_rows, const float *LE, int64_t ldLE, 
 {
     const int64_t blocks = (n_rows + 32 * RW - 1) / (32 * RW);
     if (blocks == 0) return NGCF_OK;
-    if (al)
-        layer_dense_kernel<RW, CW, NT, true><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+    if (al && d_in % NGCF_DC == 0)
+        layer_dense_kernel<RW, CW, NT, true, true><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+    else if (al)
+        layer_dense_kernel<RW, CW, NT, true, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
             LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
     else
-        layer_dense_kernel<RW, CW, NT, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+        layer_dense_kernel<RW, CW, NT, false, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
             LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
     LAUNCH_CHECK();
     return NGCF_OK;
