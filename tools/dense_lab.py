@@ -7,7 +7,7 @@ eng = pkg.engine
 dev = torch.device("cuda:0")
 n = 1_000_000
 ws = eng.Workspace()
-for d_in, d_out in ((64, 64), (128, 128), (256, 256), (512, 512), (65, 64), (130, 128)):
+for d_in, d_out in ((16, 128), (32, 128), (64, 128), (128, 128), (256, 128)):
     LE, E = (torch.randn((n, d_in), device=dev) for _ in range(2))
     W1, W2 = (torch.randn((d_out, d_in), device=dev) * 0.05 for _ in range(2))
     b1, b2 = (torch.randn((d_out,), device=dev) * 0.05 for _ in range(2))
