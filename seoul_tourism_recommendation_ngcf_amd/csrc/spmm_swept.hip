@@ -312,7 +312,7 @@ __device__ inline void swept_accumulate(const float4 (&x)[16], const SweptEntrie
 
 // Meeting point of the workgroups of one XCD after a column block.  Bounded spin: a group that is not resident
 // together only loses the L2 re-use; it never hangs and never changes the result.
-__device__ inline void swept_group_sync(unsigned *ctr, unsigned target, int max_spin)
+__device__ inline void swept_group_sync(unsigned *ctr, unsigned target, int &max_spin)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -320,6 +320,7 @@ __device__ inline void swept_group_sync(unsigned *ctr, unsigned target, int max_
         int spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < max_spin)
             __builtin_amdgcn_s_sleep(1);
+        if (max_spin > 0 && spins >= max_spin) max_spin = 0;   // the group is not resident together: stop waiting from now on
     }
     __syncthreads();
 }
