@@ -588,3 +588,47 @@ def test_full_size_c3_properties(dev):
         m = (le + E0[r]) @ W1.T + 2 * b1 + (le * E0[r]) @ W2.T + b2
         m = torch.where(m >= 0, m, 0.2 * m)
         np.testing.assert_allclose(all_E[r, 128:256].cpu().numpy(), (m / m.norm()).cpu().numpy(), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("U,I,inter,d0,layers,B", [(1, 1, 1, 5, (4,), 3), (3, 2, 0, 10, (8, 8), 4), (17, 300, 900, 15, (33, 7), 64),
+                                                    (2000, 3, 2500, 65, (65,), 4096), (64, 64, 4096, 20, (16, 16, 16, 16), 1)])
+def test_odd_shapes_against_oracle(U, I, inter, d0, layers, B, dev):
+    """Degenerate and lopsided graphs, tiny and odd widths, empty Laplacian, batch larger than the user count."""
+    pkg = _pkg()
+    g = torch.Generator().manual_seed(U * 31 + I)
+    if inter > 0:
+        key = torch.unique(torch.randint(0, U * I, (inter,), generator=g))
+        u, i = key // I, key % I
+        w = torch.rand(key.numel(), generator=g) * 4.5 + 0.5
+        coo = pkg.graphs._normalise(u, i, w, U, I)
+    else:
+        coo = {"rows": torch.empty(0, dtype=torch.int64), "cols": torch.empty(0, dtype=torch.int64), "vals": torch.empty(0)}
+    coo.update({"n_user": U, "n_item": I})
+    lap = pkg.graphs.to_sparse_coo(coo)
+    num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(5)
+    model = pkg.NGCF(d0, list(layers), 0.3, [0.1] * len(layers), 0.5, [lap], num_dict, B, dev).to(dev).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = dict(year=torch.full((B,), 18), u_id=torch.randperm(max(U, B), generator=g)[:B] % U,
+                 age=torch.randint(0, 76, (B,), generator=g), sex=torch.randint(0, 2, (B,), generator=g),
+                 month=torch.randint(0, 13, (B,), generator=g), day=torch.randint(0, 32, (B,), generator=g),
+                 dow=torch.randint(0, 7, (B,), generator=g), pos_item=torch.randint(0, I, (B,), generator=g),
+                 neg_item=torch.randint(0, I, (B,), generator=g))
+    with torch.no_grad():
+        u_e, p_e, n_e = model(node_flag=False, **{k: v.to(dev) for k, v in batch.items()})
+        loss = pkg.BPR(0.025, B)(u_e, p_e, n_e)
+    # oracle with the engine's duplicate rule (last occurrence wins), RHS from the pre-update rows
+    feats = torch.cat([sd["age_emb.weight"][batch["age"]], sd["sex_emb.weight"][batch["sex"]], sd["month_emb.weight"][batch["month"]],
+                       sd["day_emb.weight"][batch["day"]], sd["dow_emb.weight"][batch["dow"]]], 1)
+    uw = sd["user_embedding.weight"].clone()
+    rhs = uw[batch["u_id"]] * (1 - 0.5) + feats * 0.5
+    for bpos in range(B):
+        uw[batch["u_id"][bpos]] = rhs[bpos]
+    assert torch.equal(model.user_embedding.weight.detach().cpu(), uw)
+    w1, b1, w2, b2 = layer_params(sd, len(layers))
+    want = orc.propagate_torch(lap, uw, sd["item_embedding.weight"], w1, b1, w2, b2)
+    got = torch.cat((model.all_users_emb, model.all_items_emb), 0).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=ATOL, rtol=RTOL)
+    ou, op, on = orc.gather_torch(want, U, batch["u_id"], batch["pos_item"], batch["neg_item"])
+    ref_loss = float(orc.bpr_torch(ou, op, on, 0.025, B))
+    assert abs(float(loss) - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-6
