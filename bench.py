@@ -67,7 +67,22 @@ def spmm_model_a_bytes(nnz, n_rows, n_cols, d):
     return nnz * 8 + (n_rows + 1) * 8 + n_cols * d * 4 + n_rows * d * 4
 
 
-def cpu_baseline(coo, model, n_threads):
+def parity_spot_check(ref, model, coo, seed):
+    """inside the same run, compare the engine's all_E with the CPU oracle's on 4 096 random rows plus the
+    64 heaviest rows, over the columns the oracle sample covers, at the forward tolerance (atol 2e-5, rtol 2e-3)."""
+    N = ref.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(seed + 7)
+    deg = torch.bincount(coo["rows"].cpu(), minlength=N)
+    pick = torch.cat([torch.randint(0, N, (min(4096, N),), generator=g), torch.topk(deg, min(64, N)).indices]).unique()
+    got = torch.cat([model.all_users_emb, model.all_items_emb], 0)[pick.to(model.all_users_emb.device), :ref.shape[1]].cpu()
+    want = ref[pick]
+    err = (got - want).abs()
+    ok = bool((err <= 2e-5 + 2e-3 * want.abs()).all())
+    return {"rows": int(pick.numel()), "cols": int(ref.shape[1]), "max_abs_err": float(err.max()), "atol": 2e-5,
+            "rtol": 2e-3, "ok": ok, "against": "oracle/ngcf_oracle.py propagate_torch (CPU restatement of NGCF.py:120-147)"}
+
+
+def cpu_baseline(coo, model, n_threads, seed=0):
     """The reference's PyTorch CPU path (oracle/ngcf_oracle.py, bit-exact restatement) on a bounded sample:
     ONE propagation layer (layer 1 of 3) of the same graph and weights, on this node's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -79,16 +94,16 @@ def cpu_baseline(coo, model, n_threads):
     torch.set_num_threads(n_threads)
     t0 = time.perf_counter()
     with torch.no_grad():
-        orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], [sd["w1_list.0.weight"]],
-                            [sd["w1_list.0.bias"]], [sd["w2_list.0.weight"]], [sd["w2_list.0.bias"]])
+        ref = orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], [sd["w1_list.0.weight"]],
+                                  [sd["w1_list.0.bias"]], [sd["w2_list.0.weight"]], [sd["w2_list.0.bias"]])
     dt = time.perf_counter() - t0
-    return {"value": coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
+    return {"parity": parity_spot_check(ref, model, coo, seed), "value": coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
             "sample": f"1 of 3 layers (SpMM + 3 Linear + LeakyReLU + normalize + cat) of the same graph, "
                       f"nnz(L)={coo['nnz']}, d=128, torch {torch.__version__} CPU, {dt:.1f} s, single run",
             "seconds": dt}
 
 
-def cpu_baseline_full(coo, model, n_threads):
+def cpu_baseline_full(coo, model, n_threads, seed=0):
     """Seoul-sized workloads: the whole propagation (all layers) of the CPU oracle, median of 5 runs."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ngcf_oracle as orc
@@ -103,10 +118,10 @@ def cpu_baseline_full(coo, model, n_threads):
     with torch.no_grad():
         for _ in range(6):
             t0 = time.perf_counter()
-            orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], *w)
+            ref = orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], *w)
             times.append(time.perf_counter() - t0)
     dt = sorted(times[1:])[2]
-    return {"value": n_layer * coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
+    return {"parity": parity_spot_check(ref, model, coo, seed), "value": n_layer * coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
             "sample": f"whole {n_layer}-layer propagation, median of 5 after 1 warm-up, torch {torch.__version__} CPU, {dt * 1e3:.1f} ms",
             "seconds": dt}
 
@@ -240,6 +255,10 @@ def main():
         if rec and rec.get("seg_len", 0) == (args.seg_len or rec.get("seg_len", 0)):
             traffic = rec["hbm_bytes_per_spmm_launch"]
 
+    swept = [c_.swept_rows for c_ in ([csr] if world == 1 else [sh.csr_u, getattr(sh, "csr_it", None) or sh.csr_i])]
+    kernel_name = ("spmm_swept_kernel (one L.E product: a launch per row group + fix-up)" if all(swept) else
+                   "spmm_kernel + spmm_sliced_kernel (one L.E product)" if not any(swept) else
+                   "spmm_swept_kernel / spmm_kernel (one L.E product, mean over the rank's two products)")
     out = {
         "metric": "NGCF 3-layer forward: propagated edges/sec + achieved HBM GB/s, d=128",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -251,21 +270,24 @@ def main():
                    "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
                    "d": d0, "n_layers": n_layer, "batch": args.batch,
                    "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, exchange={args.exchange}"},
-        "roofline": {"bound": "hbm", "kernel": "spmm_kernel + spmm_sliced_kernel (one L.E product)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
-                     "mean_launch_ms": mean_ms,
+                     "mean_launch_ms": mean_ms, "swept_rows": swept,
                      "gather_bytes_per_launch": local_nnz / max(len(spmm_shapes), 1) * d0 * 4 if world > 1 else nnz * d0 * 4},
         "loss": float(loss),
     }
     if seoul:
         out["roofline"]["note"] = "working set is cache-resident at this size: the HBM fraction is not meaningful (SURVEY 8d)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and seoul:
-        out["cpu_baseline"] = cpu_baseline_full(coo, model, host_cores())
+        out["cpu_baseline"] = cpu_baseline_full(coo, model, host_cores(), seed)
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(coo, model, host_cores())
+        out["cpu_baseline"] = cpu_baseline(coo, model, host_cores(), seed)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and out["cpu_baseline"]:
+        out["parity"] = out["cpu_baseline"].pop("parity")     # the oracle as the checker, beside it as the baseline
+        assert out["parity"]["ok"], f"engine disagrees with the CPU oracle: {out['parity']}"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -70,15 +70,21 @@ int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx, const flo
 /* Re-plan the row segmentation: rows with more than `seg_len` stored entries are cut into
  * segments of `seg_len` entries whose partial sums are combined in a fixed order (no atomics). */
 int ngcf_csr_plan(ngcf_csr_t *csr, int32_t seg_len, void *stream);
-/* SpMM kernel choice: 0 = automatic (the L2-swept kernel for matrices with >= 2^22 stored entries and widths
- * that are multiples of 64, the row-wise gather kernel otherwise), 1 = row-wise kernel only, 2 = swept kernel
- * whenever the width allows (builds its plan on the host if missing; used by tests on small matrices). */
+/* SpMM kernel choice.  0 = row-wise gather kernels, d-sliced on the row groups whose gathered table is small
+ * (default: right for matrices that live for one product, e.g. the per-layer node-dropout matrices); 1 = row-wise
+ * kernels without d-slicing; 2 = L2-swept kernel (csrc/spmm_swept.hip) on every row group whose shape allows it
+ * (tests); 3 = L2-swept kernel on the row groups where its host-side plan expects enough L2 re-use to pay, the
+ * row-wise kernels on the rest - meant for long-lived matrices (the Laplacians of `lap_list`): building the plan
+ * costs a host pass over the entries and as much device memory again as the CSR.  Calls whose width is not a
+ * multiple of 64, that use edge dropout, or whose table spans more than 4 GiB use the row-wise kernels anyway. */
 int ngcf_csr_set_mode(ngcf_csr_t *csr, int mode, void *stream);
 void ngcf_csr_free(ngcf_csr_t *csr);
 int64_t ngcf_csr_nnz(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_rows(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_cols(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_segments(const ngcf_csr_t *csr);
+/* rows currently covered by L2-swept parts (0: every product of this CSR runs on the row-wise kernels) */
+int64_t ngcf_csr_swept_rows(const ngcf_csr_t *csr);
 /* device pointers of the CSR arrays (for tests / the transposed view) */
 const int64_t *ngcf_csr_rowptr(const ngcf_csr_t *csr);
 const int32_t *ngcf_csr_colidx(const ngcf_csr_t *csr);

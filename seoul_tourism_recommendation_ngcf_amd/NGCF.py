@@ -10,6 +10,7 @@ with the module on the CPU raises.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -17,6 +18,11 @@ import torch.nn as nn
 
 from . import engine as _eng
 from .autograd import GatherTriple, propagate_with_grad
+
+
+def _spmm_mode() -> int:
+    """SpMM kernel choice for the cached Laplacians (include/ngcf_hip.h, ngcf_csr_set_mode); NGCF_SPMM_MODE overrides."""
+    return int(os.environ.get("NGCF_SPMM_MODE", "3"))
 
 
 class NGCF(nn.Module):
@@ -110,6 +116,7 @@ class NGCF(nn.Module):
                 raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(L.shape)} and {N}x{self.emb_size})")
             rows, cols, vals = self._sorted_coo(L, dev)
             csr = _eng.LaplacianCSR.from_coo(rows, cols, vals, N, N)
+            csr.set_mode(_spmm_mode())         # long-lived matrix: worth the L2-swept plan where that pays
             self._csr_cache = {k: v for k, v in self._csr_cache.items() if year_idx not in k[:2]}
             self._csr_cache[key] = csr
         return csr
@@ -137,6 +144,7 @@ class NGCF(nn.Module):
         if csr is None:
             rows, cols, vals = self._sorted_coo(L, dev)
             csr = self._transposed_csr(torch.stack([rows, cols]), vals)
+            csr.set_mode(_spmm_mode())
             self._csr_cache[key] = csr
         return csr
 

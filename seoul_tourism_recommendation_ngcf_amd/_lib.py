@@ -33,6 +33,7 @@ PROTOTYPES = {
     "ngcf_csr_n_rows": (_i64, [_vp]),
     "ngcf_csr_n_cols": (_i64, [_vp]),
     "ngcf_csr_n_segments": (_i64, [_vp]),
+    "ngcf_csr_swept_rows": (_i64, [_vp]),
     "ngcf_csr_rowptr": (_vp, [_vp]),
     "ngcf_csr_colidx": (_vp, [_vp]),
     "ngcf_csr_vals": (_vp, [_vp]),

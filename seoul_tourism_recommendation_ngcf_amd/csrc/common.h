@@ -81,20 +81,35 @@ struct ngcf_csr {
     // row groups: maximal runs of rows whose gathered column range is small enough that d-slicing pays
     struct RowGroup { int64_t begin, end; bool sliceable; };
     std::vector<RowGroup> groups;
-    // L2-swept plan (see "swept SpMM" below); experimental, only on request
-    int mode = 0;                      // 0/1 row-wise kernels, 2 swept kernel whenever the width allows
+    // L2-swept plan (spmm_swept.hip): built on request (mode 2/3) for long-lived matrices
+    int mode = 0;                      // 0 row-wise (+ d-sliced groups), 1 row-wise only, 2 swept wherever the shape
+                                       // allows, 3 swept on the row groups where the plan expects L2 re-use to pay
+    struct SegSet {                    // rows cut into segments (device arrays, same meaning as seg_row.. above)
+        int64_t n_seg = 0, n_heavy = 0;
+        int32_t *seg_row = nullptr;
+        int64_t *seg_begin = nullptr;
+        int32_t *heavy_row = nullptr;
+        int64_t *heavy_seg_ptr = nullptr;
+    };
     struct Swept {
-        int64_t n_owners = 0, n_entries = 0, n_partial = 0, n_heavy = 0;
-        int32_t block_cols = 0, n_blocks = 0, n_rounds = 0, col_lo = 0;
-        int64_t *own_ptr = nullptr;        // device [n_owners+1]   entry range of each owner
-        int32_t *own_blk = nullptr;        // device [n_owners][n_blocks] end offset of each column block in that range
-        uint32_t *barrier = nullptr;       // device [8*32] per-XCD arrival counters (zeroed before each launch)
-        int32_t *e_col = nullptr;          // device [n_entries]    column, sorted by (column block, row) per owner
-        float *e_val = nullptr;            // device [n_entries]
-        uint8_t *e_row = nullptr;          // device [n_entries]    owner-local row id (0..15)
-        int64_t *own_dst = nullptr;        // device [n_owners*16]  >=0 output row, <0 partial -1-p, INT64_MIN unused
-        int32_t *heavy_row = nullptr;      // device [n_heavy]
-        int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1]
+        struct Part {                      // one row group handled by the swept kernel
+            int64_t row_lo = 0, row_hi = 0;
+            int waves = 0, rows_per_wave = 0;          // workgroup shape the entry lists were laid out for
+            int32_t n_rowpass = 0, n_win = 0, win_cols = 0, col_lo = 0, col_hi = 0;
+            int64_t n_slots = 0, n_partial = 0, n_heavy = 0, partial_base = 0;   // partial rows: workspace rows base..base+n
+            int64_t *tptr = nullptr;           // device [n_tasks*n_win+1] slot range of every (wave task, column window)
+            int32_t *e_pack = nullptr;         // device [n_slots] (local row << 25) | column; negative: empty slot
+            float *e_val = nullptr;            // device [n_slots]
+            int32_t *dst = nullptr;            // device [n_tasks*rows_per_wave] >=0 output row, <=-2 the part's partial row -2-p, -1 unused
+            int32_t *heavy_row = nullptr;      // device [n_heavy]   rows cut into pieces
+            int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1] their ranges of the part's partial rows
+        };
+        std::vector<Part> parts;
+        std::vector<char> group_swept;     // per entry of `groups`: handled by a part
+        SegSet out;                        // segments of the cut rows that no part covers
+        int64_t n_partial = 0;             // partial rows of all parts (they follow out.n_seg in the workspace)
+        uint32_t *barrier = nullptr;       // device [8*32] per-XCD sweep counters (zeroed before each launch)
+        int built_mode = 0;
     } swept;
 };
 
@@ -102,7 +117,8 @@ struct ngcf_csr {
 static const int32_t kDefaultSegLen = 2048;   // measured on C3: 512 -> 20.9 ms/step, 2048 -> 20.6, 4096 -> 20.5
 
 void free_swept(ngcf_csr *c);                                  // spmm_swept.hip
-int build_swept_plan(ngcf_csr *c, hipStream_t stream);         // spmm_swept.hip
+int build_swept_plan(ngcf_csr *c, hipStream_t stream);         // spmm_swept.hip (reads c->mode)
+bool swept_usable(const ngcf_csr *c, int64_t ldE, int d);       // spmm_swept.hip: can this call use the parts?
 void prof_mark(hipStream_t stream, int which);                 // spmm.hip: hipEvent around the SpMM launches
 
 // counter-based hash: the keep masks of node and message dropout are pure functions of (seed, index)
@@ -129,7 +145,7 @@ struct EdgeDrop {
 
 int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, void *workspace,
                   int64_t workspace_bytes, hipStream_t stream, const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr});
-// swept kernel launch (spmm_swept.hip); returns NGCF_OK or an error code
+// swept parts (spmm_swept.hip): kernels + fix-ups of every part; `partial` is the workspace base (rows of dp floats)
 int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, float *partial, int dp,
                  hipStream_t stream);
 

@@ -46,6 +46,13 @@ extern "C" int64_t ngcf_csr_nnz(const ngcf_csr_t *c) { return c ? c->nnz : -1; }
 extern "C" int64_t ngcf_csr_n_rows(const ngcf_csr_t *c) { return c ? c->n_rows : -1; }
 extern "C" int64_t ngcf_csr_n_cols(const ngcf_csr_t *c) { return c ? c->n_cols : -1; }
 extern "C" int64_t ngcf_csr_n_segments(const ngcf_csr_t *c) { return c ? c->n_seg : -1; }
+extern "C" int64_t ngcf_csr_swept_rows(const ngcf_csr_t *c)
+{
+    if (!c) return -1;
+    int64_t n = 0;
+    for (const auto &p : c->swept.parts) n += p.row_hi - p.row_lo;
+    return n;
+}
 extern "C" const int64_t *ngcf_csr_rowptr(const ngcf_csr_t *c) { return c ? c->rowptr : nullptr; }
 extern "C" const int32_t *ngcf_csr_colidx(const ngcf_csr_t *c) { return c ? c->colidx : nullptr; }
 extern "C" const float *ngcf_csr_vals(const ngcf_csr_t *c) { return c ? c->vals : nullptr; }
@@ -207,19 +214,20 @@ extern "C" int ngcf_csr_plan(ngcf_csr_t *c, int32_t seg_len, void *stream_)
         const int rc = build_row_groups(c, stream);
         if (rc != NGCF_OK) return rc;
     }
-    if (c->swept.n_owners == 0 && c->mode == 2) return build_swept_plan(c, stream);
+    if (c->mode >= 2) return build_swept_plan(c, stream);          // the parts follow the row groups and seg_len
+    free_swept(c);
     return NGCF_OK;
 }
 
 extern "C" int ngcf_csr_set_mode(ngcf_csr_t *c, int mode, void *stream)
 {
-    if (!c || mode < 0 || mode > 2) return fail(NGCF_ERR_ARG, "ngcf_csr_set_mode: bad argument");
+    if (!c || mode < 0 || mode > 3) return fail(NGCF_ERR_ARG, "ngcf_csr_set_mode: bad argument");
     c->mode = mode;
-    if (mode != 2) {
+    if (mode < 2) {
         free_swept(c);
         return NGCF_OK;
     }
-    if (c->swept.n_owners == 0) return build_swept_plan(c, (hipStream_t)stream);
+    if (c->swept.built_mode != mode) return build_swept_plan(c, (hipStream_t)stream);
     return NGCF_OK;
 }
 

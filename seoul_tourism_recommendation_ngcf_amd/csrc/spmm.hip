@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
 extern "C" int64_t ngcf_spmm_workspace_bytes(const ngcf_csr_t *c, int d)
 {
     if (!c || d <= 0) return -1;
-    const int64_t n_part = std::max(c->n_seg, c->swept.n_partial);
+    const int64_t n_part = std::max(c->n_seg, c->swept.out.n_seg + c->swept.n_partial);
     return align_up(n_part * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
 }
 
@@ -118,6 +118,7 @@ extern "C" int ngcf_prof_collect(int64_t *n_launches, double *total_ms)
 
 namespace {
 struct SpmmArgs {
+    bool with_swept;        // the swept parts take their row groups; the row-wise kernels take the rest
     const ngcf_csr *c;
     const float *E;
     int64_t ldE;
@@ -134,14 +135,20 @@ template <int VEC, int LPR, int CH, int U>
 int launch_spmm(const SpmmArgs &a)
 {
     const ngcf_csr *c = a.c;
-    const int64_t seg_blocks = (c->n_seg + 3) / 4;
+    // cut rows: all of them, or (beside the swept parts) those of the groups the parts do not cover
+    const int64_t n_seg = a.with_swept ? c->swept.out.n_seg : c->n_seg, n_heavy = a.with_swept ? c->swept.out.n_heavy : c->n_heavy;
+    const int32_t *seg_row = a.with_swept ? c->swept.out.seg_row : c->seg_row;
+    const int64_t *seg_begin = a.with_swept ? c->swept.out.seg_begin : c->seg_begin;
+    const int32_t *heavy_row = a.with_swept ? c->swept.out.heavy_row : c->heavy_row;
+    const int64_t *heavy_seg_ptr = a.with_swept ? c->swept.out.heavy_seg_ptr : c->heavy_seg_ptr;
+    const int64_t seg_blocks = (n_seg + 3) / 4;
     // d-slicing of the sliceable row groups needs 16-byte slices of 32 floats
     const bool can_slice = VEC == 4 && a.d % 32 == 0 && a.d >= 64 && c->mode != 1 && !getenv("NGCF_NO_SLICING");
-    prof_mark(a.stream, 0);
     bool seg_done = seg_blocks == 0;
     for (size_t g = 0; g <= c->groups.size(); ++g) {
         const bool last = g == c->groups.size();
         if (last && seg_done) break;
+        if (!last && a.with_swept && c->swept.group_swept[g]) continue;
         if (!last && can_slice && c->groups[g].sliceable) {
             const int64_t rb = (c->groups[g].end - c->groups[g].begin + 3) / 4;
             const int64_t blocks = rb * (a.d / 32);
@@ -159,17 +166,16 @@ int launch_spmm(const SpmmArgs &a)
         if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
         if (blocks > 0) {
             spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
-                c->rowptr, c->colidx, c->vals, rbeg, rend, c->seg_row, c->seg_begin, seg_done ? 0 : c->n_seg, sb, c->seg_len,
+                c->rowptr, c->colidx, c->vals, rbeg, rend, seg_row, seg_begin, seg_done ? 0 : n_seg, sb, c->seg_len,
                 a.E, a.ldE, a.d, a.out, a.ldo, a.partial, a.dp, a.dr);
             LAUNCH_CHECK();
         }
         seg_done = true;
     }
-    prof_mark(a.stream, 1);
-    if (c->n_heavy > 0) {
-        const int64_t fb = (c->n_heavy + 3) / 4;
-        spmm_fixup_kernel<VEC><<<dim3((unsigned)fb), 256, 0, a.stream>>>(c->heavy_row, c->heavy_seg_ptr, c->n_heavy,
-                                                                          a.partial, a.dp, a.d, a.out, a.ldo);
+    if (n_heavy > 0) {
+        const int64_t fb = (n_heavy + 3) / 4;
+        spmm_fixup_kernel<VEC><<<dim3((unsigned)fb), 256, 0, a.stream>>>(heavy_row, heavy_seg_ptr, n_heavy, a.partial, a.dp, a.d, a.out,
+                                                                          a.ldo);
         LAUNCH_CHECK();
     }
     return NGCF_OK;
@@ -190,37 +196,33 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
         return NGCF_OK;
     }
     const int dp = (int)align_up(d, 4);
+    const bool vec = (d % 4 == 0) && (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
+    const bool with_swept = vec && dr.n == 0 && swept_usable(c, ldE, d);
     float *partial = nullptr;
-    if (c->n_seg > 0) {
+    if (with_swept ? c->swept.out.n_seg + c->swept.n_partial > 0 : c->n_seg > 0) {
         const int64_t need = ngcf_spmm_workspace_bytes(c, d);
         if (!workspace || workspace_bytes < need)
             return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
         partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
     }
-    SpmmArgs a{c, E, ldE, d, out, ldo, partial, dp, stream, dr};
-    const bool vec = (d % 4 == 0) && (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
-    const ngcf_csr::Swept &w = c->swept;
-    if (vec && d % 64 == 0 && w.n_owners > 0 && c->mode == 2 && dr.n == 0) {
-        if (w.n_partial > 0 && !partial) {
-            const int64_t need = ngcf_spmm_workspace_bytes(c, d);
-            if (!workspace || workspace_bytes < need)
-                return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
-            partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
-        }
-        return launch_swept(c, E, ldE, d, out, ldo, partial, dp, stream);
-    }
+    SpmmArgs a{with_swept, c, E, ldE, d, out, ldo, partial, dp, stream, dr};
+    prof_mark(stream, 0);                       // one L.E product = everything between the two marks
+    int rc = NGCF_OK;
+    if (with_swept) rc = launch_swept(c, E, ldE, d, out, ldo, partial, dp, stream);
+    if (rc != NGCF_OK) return rc;
     if (vec) {
         const int nq = d / 4;
-        if (nq <= 8) return launch_spmm<4, 8, 1, 4>(a);
-        if (nq <= 16) return launch_spmm<4, 16, 1, 8>(a);
-        if (nq <= 32) return launch_spmm<4, 32, 1, 8>(a);
-        if (nq <= 64) return launch_spmm<4, 64, 1, 8>(a);
-        return launch_spmm<4, 64, 2, 4>(a);
-    }
-    if (d <= 64) return launch_spmm<1, 64, 1, 8>(a);
-    if (d <= 128) return launch_spmm<1, 64, 2, 4>(a);
-    if (d <= 256) return launch_spmm<1, 64, 4, 2>(a);
-    return launch_spmm<1, 64, 8, 1>(a);
+        if (nq <= 8) rc = launch_spmm<4, 8, 1, 4>(a);
+        else if (nq <= 16) rc = launch_spmm<4, 16, 1, 8>(a);
+        else if (nq <= 32) rc = launch_spmm<4, 32, 1, 8>(a);
+        else if (nq <= 64) rc = launch_spmm<4, 64, 1, 8>(a);
+        else rc = launch_spmm<4, 64, 2, 4>(a);
+    } else if (d <= 64) rc = launch_spmm<1, 64, 1, 8>(a);
+    else if (d <= 128) rc = launch_spmm<1, 64, 2, 4>(a);
+    else if (d <= 256) rc = launch_spmm<1, 64, 4, 2>(a);
+    else rc = launch_spmm<1, 64, 8, 1>(a);
+    prof_mark(stream, 1);
+    return rc;
 }
 
 extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,

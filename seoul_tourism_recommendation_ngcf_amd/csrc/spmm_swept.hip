@@ -1,63 +1,47 @@
-// spmm_swept.hip - the opt-in L2-swept SpMM: host plan + persistent kernel (see the section comment).
+// spmm_swept.hip - the L2-swept SpMM for long-lived matrices: host plan + persistent kernel.
+//
+// Same product LE = L.E (NGCF.py:130).  Why: on a graph without locality the row-wise kernels miss L2 on most
+// gathered rows and run at the chip's L2-miss rate (~8 TB/s of gathered bytes); rows served from L2 arrive 2-3x
+// faster (profiles/r01_window_lab.txt).  Here the gathered table is swept in column windows of a few MiB while
+// every CU works on the same window, so a table row is fetched from memory once per XCD and re-used from that
+// XCD's L2 by the other output rows that need it.
+//
+// How: a persistent grid of 256 workgroups (one per CU).  Every wave owns up to RW output rows ("wave task") whose
+// accumulators - one 64-float slice each - stay in LDS for a whole sweep, so the chip's LDS holds 100 K row slices
+// at once; d is walked slice by slice, the rows in "row passes" when they do not fit at once.  The host plan deals
+// rows (long rows in strided pieces) to the wave tasks so that all tasks carry the same number of entries, and
+// lays each task's entries out window by window.  A round = one wave instruction = four entries (16 lanes x 16 B
+// each).  The contribution of an entry is added to its LDS row with a plain read-modify-write (LDS float atomics
+// were measured 15x slower), so inside a window the plan orders the entries such that the four entries of a round
+// belong to four different rows (wrap-around rule: row after row is laid down the rounds, R = max(longest row,
+// ceil(entries / 4)) rounds per window; < 2 % empty slots on C3).  A wave touches nothing but its own LDS rows
+// and adds in list order: the result is deterministic.
+// The sweep is kept together per XCD (HW_REG_XCC_ID) by counters: a wave may enter window s once every workgroup
+// of its XCD has left window s-1-lead behind.  The spin is bounded and only serves speed - a grid that is not
+// resident together loses the L2 re-use, it never hangs and never changes the result.
+// Rows cut into pieces leave partial sums in the workspace; spmm_fixup_kernel adds them in piece order.
+// Measured on C3 (1x MI355X, d=128): item rows 1.98 ms vs 3.5 ms row-wise, user rows 2.06 vs 2.46 ms d-sliced.
 #include "spmm_device.h"
 
-void free_swept(ngcf_csr *c)
+namespace {
+constexpr int kLPE = 16;                  // lanes per entry: a 64-float slice of the gathered row
+constexpr int kSW = kLPE * 4;             // floats per slice
+constexpr int kEPR = 64 / kLPE;           // entries per round
+constexpr int kCH = 16 * kEPR;            // entries per chunk (16 rounds)
+constexpr int kSweptWGs = 256;            // one workgroup per CU
+constexpr int kRing = 8;                  // rotating sweep counters per XCD
+constexpr int kRowBits = 25;              // e_pack: column in bits 0..24, local row in bits 25..30, bit 31 = empty slot
+constexpr int kColMask = (1 << kRowBits) - 1;
+constexpr int kLdsRows = 26 * 16;         // accumulator rows per workgroup (104 KiB of LDS)
+
+int env_int(const char *name, int dflt)
 {
-    ngcf_csr::Swept &w = c->swept;
-    if (w.own_ptr) (void)hipFree(w.own_ptr);
-    if (w.own_blk) (void)hipFree(w.own_blk);
-    if (w.barrier) (void)hipFree(w.barrier);
-    if (w.e_col) (void)hipFree(w.e_col);
-    if (w.e_val) (void)hipFree(w.e_val);
-    if (w.e_row) (void)hipFree(w.e_row);
-    if (w.own_dst) (void)hipFree(w.own_dst);
-    if (w.heavy_row) (void)hipFree(w.heavy_row);
-    if (w.heavy_seg_ptr) (void)hipFree(w.heavy_seg_ptr);
-    w = ngcf_csr::Swept();
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Swept SpMM: the L2-blocked form for large matrices (same product LE = L.E, NGCF.py:130).
-//
-// Why: on a graph without locality the row-wise kernel above misses L2 on ~9 of 10 gathered rows and runs at
-// the chip's L2-miss rate (~8 TB/s of gathered bytes); rows served from L2 arrive 2-3x faster (measured with a
-// synchronised sliding window, profiles/r01_window_lab.txt).  Here the gathered table is swept in column blocks
-// that fit an XCD's 4 MiB L2 while every CU works on the same block, so a table row is fetched from memory
-// once per XCD and re-used from L2 by the other output rows of that XCD that need it.
-//
-// How: a persistent grid of 256 workgroups (one per CU, 512 threads, 128 KiB of LDS).  Output rows are handed to
-// "owners"; an owner is a quarter-wave (16 lanes x 16 B = one 64-float slice of a row) that keeps up to 16
-// accumulator rows in LDS and walks its own edge list, which the host plan has sorted by (column block, row)
-// and balanced so that every owner has about the same work in every block.  The walk is software-pipelined:
-// list entries are fetched two 16-entry chunks ahead, the 16 gathers of the next chunk are issued before the
-// current chunk is accumulated.  After each column block the workgroups of one XCD (HW_REG_XCC_ID) meet at a
-// counter barrier whose spin is bounded: the barrier only keeps the sweep together for speed, correctness never
-// depends on it (an owner touches nothing but its own LDS rows and adds in list order: deterministic result).
-// Rows longer than the per-owner budget are dealt round-robin to several pieces whose partial sums are combined
-// by spmm_fixup_kernel in a fixed order.  A slice is 64 floats, so d must be a multiple of 64 (other widths use
-// the row-wise kernel); slices and owner rounds are walked one after the other inside the kernel.
-// Status: opt-in (ngcf_csr_set_mode(csr, 2)).  On the C3 item rows it reaches 3.2 ms against 3.5-3.7 ms for the
-// row-wise kernel (69 % L2 hits), still far from the 1.3 ms of a perfectly synchronised sweep: with 8 waves per
-// CU the per-entry run/flush logic and the barrier imbalance dominate.
-// ---------------------------------------------------------------------------------------------
-static const int kSweptRPO = 16;                 // accumulator rows per owner
-static const int kSweptOwnersPerWG = 32;         // 8 waves x 4 quarter-waves
-static const int kSweptWGs = 256;                // one 512-thread workgroup per CU (128 KiB of LDS)
-static const int kSweptGroups = 8;               // XCDs
-static const int64_t kSweptUnused = INT64_MIN;
-
-static int32_t swept_block_cols()
-{
-    // columns per block: block bytes / (64 floats * 4 B); default 2 MiB of table slice per block
-    const char *e = getenv("NGCF_SWEPT_BLOCK_KB");
-    int64_t kb = e ? atoll(e) : 2048;
-    if (kb < 16) kb = 16;
-    return (int32_t)std::max<int64_t>(kb * 1024 / 256, 64);
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 template <typename F>
-static void parallel_for(int64_t n, F &&fn)
+void parallel_for(int64_t n, F &&fn)
 {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
@@ -76,161 +60,312 @@ static void parallel_for(int64_t n, F &&fn)
     for (auto &t : th) t.join();
 }
 
-int build_swept_plan(ngcf_csr *c, hipStream_t stream)
+void free_part(ngcf_csr::Swept::Part &p)
 {
-    free_swept(c);
-    ngcf_csr::Swept &w = c->swept;
-    const int64_t n_rows = c->n_rows, nnz = c->nnz;
-    if (n_rows == 0) return NGCF_OK;
-    std::vector<int64_t> rp((size_t)n_rows + 1);
-    std::vector<int32_t> col((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
-    HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
-    if (nnz > 0) {
-        HIP_TRY(hipMemcpyAsync(col.data(), c->colidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(val.data(), c->vals, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
-    }
+    if (p.tptr) (void)hipFree(p.tptr);
+    if (p.e_pack) (void)hipFree(p.e_pack);
+    if (p.e_val) (void)hipFree(p.e_val);
+    if (p.dst) (void)hipFree(p.dst);
+    if (p.heavy_row) (void)hipFree(p.heavy_row);
+    if (p.heavy_seg_ptr) (void)hipFree(p.heavy_seg_ptr);
+    p = ngcf_csr::Swept::Part();
+}
+
+void free_segset(ngcf_csr::SegSet &s)
+{
+    if (s.seg_row) (void)hipFree(s.seg_row);
+    if (s.seg_begin) (void)hipFree(s.seg_begin);
+    if (s.heavy_row) (void)hipFree(s.heavy_row);
+    if (s.heavy_seg_ptr) (void)hipFree(s.heavy_seg_ptr);
+    s = ngcf_csr::SegSet();
+}
+
+template <typename T>
+int upload(T **dptr, const std::vector<T> &h, hipStream_t stream)
+{
+    HIP_TRY(hipMalloc(dptr, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    if (!h.empty()) HIP_TRY(hipMemcpyAsync(*dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, stream));
+    return NGCF_OK;
+}
+
+// entries begin+off, begin+off+step, ... < end of one row.  A long row is dealt out to its pieces round-robin so
+// that every piece covers the whole column range evenly (a contiguous cut would pile a piece's work into a few windows)
+struct Piece {
+    int64_t row;            // >= 0 row of the part, < 0 partial row -1-p of the part
+    int64_t begin, end, count;
+    int32_t off, step;
+};
+
+// Plan of the rows [row_lo, row_hi).  Leaves part.waves == 0 when the part is not worth it (mode 3) or the shape does
+// not fit the entry encoding.
+int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hipStream_t stream, ngcf_csr::Swept::Part &part)
+{
+    const int64_t n = row_hi - row_lo;
+    if (n <= 0) return NGCF_OK;
+    std::vector<int64_t> rp((size_t)n + 1);
+    HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr + row_lo, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-
-    const int64_t per_round = (int64_t)kSweptOwnersPerWG * kSweptWGs;       // 8192 owners are resident at a time
-    const int64_t rounds = std::max<int64_t>(1, (n_rows + per_round * 13 - 1) / (per_round * 13));
-    const int64_t target = per_round * rounds;
-    int64_t T = std::max<int64_t>(64, (nnz + target - 1) / target);
-    w.block_cols = swept_block_cols();
-
-    // entries begin+off, begin+off+step, ... < end.  A long row is dealt out to its pieces round-robin so that every
-    // piece covers the whole column range evenly (a contiguous cut would pile one piece's work into a few blocks)
-    struct Piece { int64_t begin, end, dst, off, step; int64_t count() const { return end - begin <= off ? 0 : (end - begin - off + step - 1) / step; } };
+    const int64_t e0 = rp[0], nnz = rp[(size_t)n] - e0;
+    if (nnz <= 0) return NGCF_OK;
+    if (!force && nnz < ((int64_t)1 << 22)) return NGCF_OK;          // small products are launch-bound, not L2-bound
+    std::vector<int32_t> col((size_t)nnz);
+    std::vector<float> val((size_t)nnz);
+    HIP_TRY(hipMemcpyAsync(col.data(), c->colidx + e0, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(val.data(), c->vals + e0, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (auto &x : rp) x -= e0;
+    int32_t col_lo = INT32_MAX, col_hi = 0;
+    for (int64_t x = 0; x < nnz; ++x) {
+        col_lo = std::min(col_lo, col[(size_t)x]);
+        col_hi = std::max(col_hi, col[(size_t)x]);
+    }
+    if (col_hi > kColMask) return NGCF_OK;                           // column does not fit the packed entry
+    // workgroup shape: many row passes mean short wave tasks, whose fixed cost halves with 8 longer-lived waves
+    const int64_t cap = (int64_t)kSweptWGs * kLdsRows;               // output rows resident in LDS at a time
+    const int waves = (n + cap - 1) / cap >= 3 ? 8 : 16;
+    const int RW = kLdsRows / waves;
+    const int64_t n_wave_slots = (int64_t)kSweptWGs * waves;
+    if (!force) {
+        // expected uses of a fetched table row inside one XCD during one sweep: its column degree times the share
+        // of the output rows that the XCD holds in LDS.  Below ~3 the sweep costs more than the misses it saves;
+        // a table slice that fits the L2s anyway needs no sweep either.
+        const double span = (double)col_hi - col_lo + 1;
+        const double reuse = (double)nnz / span * std::min(1.0, (double)(cap / 8) / (double)n);
+        if (reuse < 3.0 || span * kSW * 4 < (double)(8 << 20)) return NGCF_OK;
+    }
+    // 1) pieces and wave tasks: all tasks get the same number of entries and at most RW rows
+    int64_t n_rowpass = std::max<int64_t>(1, (n + cap - 1) / cap), n_tasks = 0, T = 0, n_partial = 0;
     std::vector<Piece> pieces;
     std::vector<int32_t> heavy_row;
-    std::vector<int64_t> heavy_ptr, own_first;
-    int64_t n_partial = 0;
-    for (int attempt = 0; attempt < 40; ++attempt) {
-        // 1) pieces: a row, or a <=T-entry cut of a long row (partial sums, combined in piece order)
+    std::vector<int64_t> heavy_ptr;
+    for (;; ++n_rowpass) {
+        n_tasks = n_rowpass * n_wave_slots;
+        T = std::max<int64_t>(64, (nnz + n_tasks - 1) / n_tasks);
+        const int64_t Tp = std::max<int64_t>(64, T / 4);            // rows are cut well below a task's share: tasks mix freely
         pieces.clear();
         heavy_row.clear();
         heavy_ptr.assign(1, 0);
         n_partial = 0;
-        for (int64_t r = 0; r < n_rows; ++r) {
-            const int64_t b = rp[r], e = rp[r + 1], len = e - b;
-            if (len <= T) {
-                pieces.push_back({b, e, r, 0, 1});
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t b = rp[(size_t)r], e = rp[(size_t)r + 1], len = e - b;
+            if (len <= Tp) {
+                pieces.push_back({r, b, e, len, 0, 1});
             } else {
-                const int64_t k = (len + T - 1) / T;
-                heavy_row.push_back((int32_t)r);
-                for (int64_t j = 0; j < k; ++j) pieces.push_back({b, e, -1 - n_partial++, j, k});
+                const int64_t k = (len + Tp - 1) / Tp;
+                heavy_row.push_back((int32_t)(row_lo + r));
+                for (int64_t j = 0; j < k; ++j) pieces.push_back({-1 - n_partial++, b, e, (len - j + k - 1) / k, (int32_t)j, (int32_t)k});
                 heavy_ptr.push_back(n_partial);
             }
         }
-        // 2) owners: consecutive pieces until the entry budget or kSweptRPO rows are reached
-        own_first.assign(1, 0);
-        int64_t edges = 0;
-        int rows_in = 0;
-        for (size_t i = 0; i < pieces.size(); ++i) {
-            const int64_t len = pieces[i].count();
-            if (rows_in == kSweptRPO || (rows_in > 0 && edges + len > T)) {
-                own_first.push_back((int64_t)i);
-                edges = 0;
-                rows_in = 0;
-            }
-            edges += len;
-            ++rows_in;
+        if ((int64_t)pieces.size() <= n_tasks * RW) break;
+        if (n_rowpass > (int64_t)1 << 20) return fail(NGCF_ERR_ARG, "swept plan: cannot place %zu pieces", pieces.size());
+    }
+    if (n_tasks * RW >= (int64_t)1 << 31 || n_partial >= ((int64_t)1 << 31) - 2) return fail(NGCF_ERR_ARG, "swept plan: matrix too large");
+    // level by level, heaviest piece -> lightest task (every task gets at most one piece per level)
+    std::vector<int64_t> order(pieces.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return pieces[(size_t)a].count > pieces[(size_t)b].count; });
+    std::vector<int64_t> load((size_t)n_tasks, 0), by_load((size_t)n_tasks);
+    std::vector<int64_t> task_piece((size_t)(n_tasks * RW), -1);    // [task][local row] -> piece
+    for (int64_t lvl = 0; lvl * n_tasks < (int64_t)pieces.size(); ++lvl) {
+        std::iota(by_load.begin(), by_load.end(), 0);
+        std::stable_sort(by_load.begin(), by_load.end(), [&](int64_t a, int64_t b) { return load[(size_t)a] < load[(size_t)b]; });
+        const int64_t lo = lvl * n_tasks, hi = std::min<int64_t>((int64_t)pieces.size(), lo + n_tasks);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t t = by_load[(size_t)(i - lo)];
+            task_piece[(size_t)(t * RW + lvl)] = order[(size_t)i];
+            load[(size_t)t] += pieces[(size_t)order[(size_t)i]].count;
         }
-        own_first.push_back((int64_t)pieces.size());
-        if ((int64_t)own_first.size() - 1 <= target) break;
-        T += std::max<int64_t>(1, T / 16);          // too many owners for the resident grid: raise the budget
     }
-    const int64_t n_owners = (int64_t)own_first.size() - 1;
-    const int64_t n_owners_pad = align_up(n_owners, per_round);
-    int32_t col_lo = INT32_MAX, col_hi = 0;
-    for (int64_t x = 0; x < nnz; ++x) {
-        col_lo = std::min(col_lo, col[x]);
-        col_hi = std::max(col_hi, col[x]);
-    }
-    if (nnz == 0) col_lo = 0;
-    w.col_lo = col_lo;
-    const int64_t n_blocks = std::max<int64_t>(1, ((int64_t)col_hi - col_lo + w.block_cols) / w.block_cols);
-    std::vector<int64_t> own_ptr((size_t)n_owners_pad + 1, 0);
-    std::vector<int64_t> own_dst((size_t)n_owners_pad * kSweptRPO, kSweptUnused);
-    for (int64_t o = 0; o < n_owners; ++o) {
-        int64_t cnt = 0;
-        for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
-            cnt += pieces[i].count();
-            own_dst[(size_t)(o * kSweptRPO + (i - own_first[o]))] = pieces[i].dst;
+    // 2) column windows and the slot layout of every (task, window) bucket
+    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", 4096);
+    if (win_kb < 16) win_kb = 16;
+    const int32_t win_cols = (int32_t)std::max<int64_t>(64, win_kb * 1024 / (kSW * 4));
+    const int64_t n_win = ((int64_t)col_hi - col_lo) / win_cols + 1;
+    if (n_tasks * n_win >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "swept plan: too many windows");
+    std::vector<int64_t> tptr((size_t)(n_tasks * n_win) + 1, 0);
+    auto bucket_hist = [&](int64_t t, std::vector<int32_t> &hist) {   // entries per (window, local row) of task t
+        std::fill(hist.begin(), hist.end(), 0);
+        for (int lr = 0; lr < RW; ++lr) {
+            const int64_t pi = task_piece[(size_t)(t * RW + lr)];
+            if (pi < 0) continue;
+            const Piece &pc = pieces[(size_t)pi];
+            for (int64_t x = pc.begin + pc.off; x < pc.end; x += pc.step)
+                hist[(size_t)((col[(size_t)x] - col_lo) / win_cols) * RW + lr]++;
         }
-        if (cnt >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "swept plan: owner list too long");
-        own_ptr[(size_t)o + 1] = own_ptr[(size_t)o] + cnt;
-    }
-    for (int64_t o = n_owners; o < n_owners_pad; ++o) own_ptr[(size_t)o + 1] = own_ptr[(size_t)o];
-    // 3) per owner: stable counting sort of its entries by (column block, local row); block offsets kept
-    std::vector<int32_t> e_col((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<float> e_val((size_t)std::max<int64_t>(nnz, 1));
-    std::vector<uint8_t> e_row((size_t)std::max<int64_t>(nnz, 1));
-    const int32_t bc = w.block_cols;
-    std::vector<int32_t> own_blk((size_t)n_owners_pad * (size_t)n_blocks, 0);
-    parallel_for(n_owners, [&](int64_t lo, int64_t hi) {
-        std::vector<int64_t> hist((size_t)n_blocks * kSweptRPO + 1);
-        for (int64_t o = lo; o < hi; ++o) {
-            std::fill(hist.begin(), hist.end(), 0);
-            for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
-                const int lr = (int)(i - own_first[o]);
-                for (int64_t x = pieces[i].begin + pieces[i].off; x < pieces[i].end; x += pieces[i].step)
-                    hist[(size_t)((col[x] - col_lo) / bc) * kSweptRPO + lr + 1]++;
+    };
+    // rounds of a bucket: R = max(longest row, ceil(entries / 4)); row after row is laid down the rounds, so the
+    // entries of one row never share a round (they are read-modify-written in LDS without atomics)
+    parallel_for(n_tasks, [&](int64_t lo, int64_t hi) {
+        std::vector<int32_t> hist((size_t)n_win * RW);
+        for (int64_t t = lo; t < hi; ++t) {
+            bucket_hist(t, hist);
+            for (int64_t w = 0; w < n_win; ++w) {
+                int64_t total = 0, longest = 0;
+                for (int lr = 0; lr < RW; ++lr) {
+                    total += hist[(size_t)w * RW + lr];
+                    longest = std::max<int64_t>(longest, hist[(size_t)w * RW + lr]);
+                }
+                tptr[(size_t)(t * n_win + w) + 1] = std::max(longest, (total + kEPR - 1) / kEPR) * kEPR;
             }
-            for (size_t k = 1; k < hist.size(); ++k) hist[k] += hist[k - 1];
-            for (int64_t bq = 0; bq < n_blocks; ++bq)      // where block bq ends inside this owner's list
-                own_blk[(size_t)o * (size_t)n_blocks + (size_t)bq] = (int32_t)hist[(size_t)(bq + 1) * kSweptRPO];
-            const int64_t base = own_ptr[(size_t)o];
-            for (int64_t i = own_first[o]; i < own_first[o + 1]; ++i) {
-                const int lr = (int)(i - own_first[o]);
-                for (int64_t x = pieces[i].begin + pieces[i].off; x < pieces[i].end; x += pieces[i].step) {
-                    const int64_t pos = base + hist[(size_t)((col[x] - col_lo) / bc) * kSweptRPO + lr]++;
-                    e_col[(size_t)pos] = col[x];
-                    e_val[(size_t)pos] = val[x];
-                    e_row[(size_t)pos] = (uint8_t)lr;
+        }
+    });
+    for (size_t i = 1; i < tptr.size(); ++i) tptr[i] += tptr[i - 1];
+    const int64_t n_slots = tptr.back();
+    std::vector<int32_t> e_pack((size_t)std::max<int64_t>(n_slots, 1), INT32_MIN);
+    std::vector<float> e_val((size_t)std::max<int64_t>(n_slots, 1), 0.f);
+    parallel_for(n_tasks, [&](int64_t lo, int64_t hi) {
+        std::vector<int32_t> hist((size_t)n_win * RW);
+        std::vector<int64_t> rounds((size_t)n_win);
+        for (int64_t t = lo; t < hi; ++t) {
+            bucket_hist(t, hist);
+            for (int64_t w = 0; w < n_win; ++w) {                   // hist -> first list position of every row in its bucket
+                rounds[(size_t)w] = (tptr[(size_t)(t * n_win + w) + 1] - tptr[(size_t)(t * n_win + w)]) / kEPR;
+                int32_t run = 0;
+                for (int lr = 0; lr < RW; ++lr) {
+                    const int32_t cnt = hist[(size_t)w * RW + lr];
+                    hist[(size_t)w * RW + lr] = run;
+                    run += cnt;
+                }
+            }
+            for (int lr = 0; lr < RW; ++lr) {
+                const int64_t pi = task_piece[(size_t)(t * RW + lr)];
+                if (pi < 0) continue;
+                const Piece &pc = pieces[(size_t)pi];
+                for (int64_t x = pc.begin + pc.off; x < pc.end; x += pc.step) {
+                    const int64_t w = (col[(size_t)x] - col_lo) / win_cols;
+                    const int64_t k = hist[(size_t)w * RW + lr]++, R = rounds[(size_t)w];
+                    const int64_t pos = tptr[(size_t)(t * n_win + w)] + (k % R) * kEPR + k / R;
+                    e_pack[(size_t)pos] = (int32_t)((uint32_t)lr << kRowBits) | col[(size_t)x];
+                    e_val[(size_t)pos] = val[(size_t)x];
                 }
             }
         }
     });
+    std::vector<int32_t> dst((size_t)(n_tasks * RW), -1);
+    for (size_t i = 0; i < dst.size(); ++i) {
+        if (task_piece[i] < 0) continue;
+        const int64_t r = pieces[(size_t)task_piece[i]].row;
+        dst[i] = r >= 0 ? (int32_t)(row_lo + r) : (int32_t)(-2 - (-1 - r));
+    }
     if (getenv("NGCF_SWEPT_DEBUG")) {
-        int64_t mx = 0, nz = 0;
-        for (int64_t o = 0; o < n_owners; ++o) {
-            mx = std::max(mx, own_ptr[(size_t)o + 1] - own_ptr[(size_t)o]);
-            nz += own_ptr[(size_t)o + 1] > own_ptr[(size_t)o];
+        int64_t mx = 0, mn = INT64_MAX;
+        for (int64_t t = 0; t < n_tasks; ++t) {
+            const int64_t s = tptr[(size_t)((t + 1) * n_win)] - tptr[(size_t)(t * n_win)];
+            mx = std::max(mx, s);
+            mn = std::min(mn, s);
         }
-        fprintf(stderr, "[swept plan] rows %lld nnz %lld owners %lld (pad %lld, non-empty %lld) rounds %lld T %lld max/owner %lld "
-                        "pieces %zu partial %lld blocks %lld x %d cols\n", (long long)n_rows, (long long)nnz, (long long)n_owners,
-                (long long)n_owners_pad, (long long)nz, (long long)(n_owners_pad / per_round), (long long)T, (long long)mx,
-                pieces.size(), (long long)n_partial, (long long)n_blocks, (int)bc);
+        fprintf(stderr, "[swept plan] rows [%lld, %lld) nnz %lld cols [%d, %d]: %d waves x %d rows, %lld row passes, %lld windows x %d "
+                        "cols, T %lld, pieces %zu (partial %lld), slots %lld (+%.1f%%), per task %lld..%lld\n",
+                (long long)row_lo, (long long)row_hi, (long long)nnz, col_lo, col_hi, waves, RW, (long long)n_rowpass, (long long)n_win,
+                win_cols, (long long)T, pieces.size(), (long long)n_partial, (long long)n_slots,
+                100.0 * (double)(n_slots - nnz) / (double)nnz, (long long)mn, (long long)mx);
     }
-    // 4) upload
-    w.n_owners = n_owners_pad;
-    w.n_rounds = (int32_t)(n_owners_pad / per_round);
-    w.n_blocks = (int32_t)n_blocks;
-    w.n_entries = nnz;
-    w.n_partial = n_partial;
-    w.n_heavy = (int64_t)heavy_row.size();
-    HIP_TRY(hipMalloc(&w.own_ptr, sizeof(int64_t) * own_ptr.size()));
-    HIP_TRY(hipMalloc(&w.own_dst, sizeof(int64_t) * own_dst.size()));
-    HIP_TRY(hipMalloc(&w.own_blk, sizeof(int32_t) * own_blk.size()));
-    HIP_TRY(hipMalloc(&w.barrier, sizeof(uint32_t) * 32 * kSweptGroups));
-    HIP_TRY(hipMemcpyAsync(w.own_blk, own_blk.data(), sizeof(int32_t) * own_blk.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMalloc(&w.e_col, sizeof(int32_t) * e_col.size()));
-    HIP_TRY(hipMalloc(&w.e_val, sizeof(float) * e_val.size()));
-    HIP_TRY(hipMalloc(&w.e_row, e_row.size()));
-    HIP_TRY(hipMemcpyAsync(w.own_ptr, own_ptr.data(), sizeof(int64_t) * own_ptr.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(w.own_dst, own_dst.data(), sizeof(int64_t) * own_dst.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(w.e_col, e_col.data(), sizeof(int32_t) * e_col.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(w.e_val, e_val.data(), sizeof(float) * e_val.size(), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(w.e_row, e_row.data(), e_row.size(), hipMemcpyHostToDevice, stream));
-    if (w.n_heavy > 0) {
-        HIP_TRY(hipMalloc(&w.heavy_row, sizeof(int32_t) * heavy_row.size()));
-        HIP_TRY(hipMalloc(&w.heavy_seg_ptr, sizeof(int64_t) * heavy_ptr.size()));
-        HIP_TRY(hipMemcpyAsync(w.heavy_row, heavy_row.data(), sizeof(int32_t) * heavy_row.size(), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(w.heavy_seg_ptr, heavy_ptr.data(), sizeof(int64_t) * heavy_ptr.size(), hipMemcpyHostToDevice, stream));
+    // 3) upload
+    part.row_lo = row_lo;
+    part.row_hi = row_hi;
+    part.rows_per_wave = RW;
+    part.n_rowpass = (int32_t)n_rowpass;
+    part.n_win = (int32_t)n_win;
+    part.win_cols = win_cols;
+    part.col_lo = col_lo;
+    part.col_hi = col_hi;
+    part.n_slots = n_slots;
+    part.n_partial = n_partial;
+    part.n_heavy = (int64_t)heavy_row.size();
+    int rc = upload(&part.tptr, tptr, stream);
+    if (rc == NGCF_OK) rc = upload(&part.e_pack, e_pack, stream);
+    if (rc == NGCF_OK) rc = upload(&part.e_val, e_val, stream);
+    if (rc == NGCF_OK) rc = upload(&part.dst, dst, stream);
+    if (rc == NGCF_OK && part.n_heavy > 0) rc = upload(&part.heavy_row, heavy_row, stream);
+    if (rc == NGCF_OK && part.n_heavy > 0) rc = upload(&part.heavy_seg_ptr, heavy_ptr, stream);
+    if (rc == NGCF_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(NGCF_ERR_HIP, "swept plan: upload failed");
+    if (rc != NGCF_OK) {
+        free_part(part);
+        return rc;
     }
-    HIP_TRY(hipStreamSynchronize(stream));
+    part.waves = waves;
     return NGCF_OK;
+}
+}  // namespace
+
+void free_swept(ngcf_csr *c)
+{
+    ngcf_csr::Swept &w = c->swept;
+    for (auto &p : w.parts) free_part(p);
+    free_segset(w.out);
+    if (w.barrier) (void)hipFree(w.barrier);
+    w = ngcf_csr::Swept();
+}
+
+// Builds the parts for c->mode (2: every row group whose shape allows it, 3: the groups where re-use is expected) and
+// the segment set of the cut rows that stay with the row-wise kernels.  Workspace rows: [those segments][part 0's
+// partial rows][part 1's]...
+int build_swept_plan(ngcf_csr *c, hipStream_t stream)
+{
+    free_swept(c);
+    ngcf_csr::Swept &w = c->swept;
+    w.built_mode = c->mode;
+    if (c->mode < 2 || c->n_rows == 0 || c->nnz == 0) return NGCF_OK;
+    w.group_swept.assign(c->groups.size(), 0);
+    for (size_t g = 0; g < c->groups.size(); ++g) {
+        ngcf_csr::Swept::Part p;
+        const int rc = build_part(c, c->groups[g].begin, c->groups[g].end, c->mode == 2, stream, p);
+        if (rc != NGCF_OK) {
+            free_swept(c);
+            return rc;
+        }
+        if (p.waves == 0) continue;
+        w.group_swept[g] = 1;
+        w.parts.push_back(p);
+    }
+    if (w.parts.empty()) return NGCF_OK;
+    std::vector<int64_t> rp((size_t)c->n_rows + 1);
+    HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int32_t> seg_row, heavy_row;
+    std::vector<int64_t> seg_begin, heavy_ptr(1, 0);
+    for (size_t g = 0; g < c->groups.size(); ++g) {
+        if (w.group_swept[g]) continue;
+        for (int64_t r = c->groups[g].begin; r < c->groups[g].end; ++r) {
+            if (rp[(size_t)r + 1] - rp[(size_t)r] <= c->seg_len) continue;
+            heavy_row.push_back((int32_t)r);
+            for (int64_t b = rp[(size_t)r]; b < rp[(size_t)r + 1]; b += c->seg_len) {
+                seg_row.push_back((int32_t)r);
+                seg_begin.push_back(b);
+            }
+            heavy_ptr.push_back((int64_t)seg_row.size());
+        }
+    }
+    w.out.n_seg = (int64_t)seg_row.size();
+    w.out.n_heavy = (int64_t)heavy_row.size();
+    int64_t base = w.out.n_seg;
+    for (auto &p : w.parts) {
+        p.partial_base = base;
+        base += p.n_partial;
+        w.n_partial += p.n_partial;
+    }
+    int rc = NGCF_OK;
+    if (w.out.n_seg > 0) {
+        rc = upload(&w.out.seg_row, seg_row, stream);
+        if (rc == NGCF_OK) rc = upload(&w.out.seg_begin, seg_begin, stream);
+        if (rc == NGCF_OK) rc = upload(&w.out.heavy_row, heavy_row, stream);
+        if (rc == NGCF_OK) rc = upload(&w.out.heavy_seg_ptr, heavy_ptr, stream);
+    }
+    if (rc == NGCF_OK && (hipMalloc(&w.barrier, sizeof(uint32_t) * 32 * 8) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
+        rc = fail(NGCF_ERR_HIP, "swept plan: allocation failed");
+    if (rc != NGCF_OK) free_swept(c);
+    return rc;
+}
+
+// The parts gather with 32-bit byte offsets: the gathered rows must lie within 4 GiB of the table base
+bool swept_usable(const ngcf_csr *c, int64_t ldE, int d)
+{
+    const ngcf_csr::Swept &w = c->swept;
+    if (w.parts.empty() || c->mode < 2 || d % kSW != 0) return false;
+    for (const auto &p : w.parts)
+        if (((int64_t)p.col_hi + 1) * ldE * 4 > (int64_t)UINT32_MAX) return false;
+    return true;
 }
 
 // value of lane U of this lane's 16-lane row (DPP row_newbcast: one VALU op, no LDS round trip)
@@ -243,188 +378,183 @@ template <int U> __device__ inline float row_bcast(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + U, 0xf, 0xf, false));
 }
 
-// add a 16-lane x float4 accumulator into the owner's LDS row (plain read-modify-write: only this quarter-wave
-// ever touches the row; LDS float atomics were measured slower and erratic here)
-__device__ inline void swept_flush(float *__restrict__ rowp, float4 a)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// RW accumulator rows per wave, NW waves per workgroup (NW*RW*256 B of LDS)
+template <int RW, int NW>
+__global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__restrict__ tptr, const int32_t *__restrict__ e_pack,
+                                                             const float *__restrict__ e_val, const int32_t *__restrict__ dst,
+                                                             int n_rowpass, int n_win, int n_slices, const float *__restrict__ E,
+                                                             int64_t ldE, float *__restrict__ out, int64_t ldo,
+                                                             float *__restrict__ partial, int dp, unsigned *bar, int max_spin, int lead)
 {
-    float4 *p = reinterpret_cast<float4 *>(rowp);
-    float4 t = *p;
-    t.x += a.x;
-    t.y += a.y;
-    t.z += a.z;
-    t.w += a.w;
-    *p = t;
-}
-
-#define NGCF_SWEPT_THREADS (kSweptOwnersPerWG * 16)
-
-// entries k*16 .. k*16+15 of an owner's list: lane l keeps entry l (column, value, local row)
-struct SweptEntries {
-    int c, r, cnt;
-    float v;
-};
-
-__device__ inline SweptEntries swept_load_entries(const int32_t *__restrict__ e_col, const float *__restrict__ e_val,
-                                                  const uint8_t *__restrict__ e_row, int64_t pos, int64_t end, int l, int idle_col)
-{
-    SweptEntries e;
-    const int64_t left = end - pos;
-    e.cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
-    e.c = idle_col;
-    e.r = 0;
-    e.v = 0.f;
-    if (l < e.cnt) {
-        e.c = e_col[pos + l];
-        e.v = e_val[pos + l];
-        e.r = e_row[pos + l];
-    }
-    return e;
-}
-
-// issue the 16 gathers of a chunk; idle slots re-read the chunk's first row (an L2 hit), never column 0
-__device__ inline void swept_issue(float4 (&x)[16], const SweptEntries &e, int l, const float *__restrict__ Es, int64_t ldE)
-{
-    const int c0 = row_bcast<0>(e.c);
-    const int c = l < e.cnt ? e.c : c0;
-#define NGCF_GATHER(u) x[u] = *reinterpret_cast<const float4 *>(Es + (int64_t)row_bcast<u>(c) * ldE);
-    NGCF_GATHER(0) NGCF_GATHER(1) NGCF_GATHER(2) NGCF_GATHER(3) NGCF_GATHER(4) NGCF_GATHER(5) NGCF_GATHER(6) NGCF_GATHER(7)
-    NGCF_GATHER(8) NGCF_GATHER(9) NGCF_GATHER(10) NGCF_GATHER(11) NGCF_GATHER(12) NGCF_GATHER(13) NGCF_GATHER(14) NGCF_GATHER(15)
-#undef NGCF_GATHER
-}
-
-// consecutive entries of one row are summed in registers and added to the owner's LDS row when the row changes
-__device__ inline void swept_accumulate(const float4 (&x)[16], const SweptEntries &e, float *__restrict__ myacc, int &cur, float4 &a)
-{
-#define NGCF_ACCUM(u)                                   \
-    if (u < e.cnt) {                                    \
-        const int rr = row_bcast<u>(e.r);               \
-        if (rr != cur) {                                \
-            swept_flush(myacc + cur * 64, a);           \
-            a = vzero4();                               \
-            cur = rr;                                   \
-        }                                               \
-        a = vfma(row_bcast<u>(e.v), x[u], a);           \
-    }
-    NGCF_ACCUM(0) NGCF_ACCUM(1) NGCF_ACCUM(2) NGCF_ACCUM(3) NGCF_ACCUM(4) NGCF_ACCUM(5) NGCF_ACCUM(6) NGCF_ACCUM(7)
-    NGCF_ACCUM(8) NGCF_ACCUM(9) NGCF_ACCUM(10) NGCF_ACCUM(11) NGCF_ACCUM(12) NGCF_ACCUM(13) NGCF_ACCUM(14) NGCF_ACCUM(15)
-#undef NGCF_ACCUM
-}
-
-// Meeting point of the workgroups of one XCD after a column block.  Bounded spin: a group that is not resident
-// together only loses the L2 re-use; it never hangs and never changes the result.
-__device__ inline void swept_group_sync(unsigned *ctr, unsigned target, int &max_spin)
-{
-    __syncthreads();
+    __shared__ float acc_lds[NW * RW * kSW];
+    __shared__ unsigned wg_cnt[kRing];
+    __shared__ int perm_lds;                    // highest sweep step this workgroup knows to be permitted
+    __shared__ unsigned xcc_id;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, p = lane & 15;     // entry slot in the round, position in the slice
+    const int held = p * kEPR + g;              // chunk entry this lane keeps: round u = lane u of every 16-lane row
+    float *wacc = acc_lds + wave * (RW * kSW);
+    if (threadIdx.x < kRing) wg_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < max_spin)
-            __builtin_amdgcn_s_sleep(1);
-        if (max_spin > 0 && spins >= max_spin) max_spin = 0;   // the group is not resident together: stop waiting from now on
+        xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID
+        perm_lds = lead;                        // steps 0..lead wait for nobody
     }
     __syncthreads();
-}
-
-__global__ __launch_bounds__(NGCF_SWEPT_THREADS) void spmm_swept_kernel(
-    const int64_t *__restrict__ own_ptr, const int32_t *__restrict__ own_blk, const int32_t *__restrict__ e_col,
-    const float *__restrict__ e_val, const uint8_t *__restrict__ e_row, const int64_t *__restrict__ own_dst, int n_rounds,
-    int n_blocks, int n_slices, const float *__restrict__ E, int64_t ldE, float *__restrict__ out, int64_t ldo,
-    float *__restrict__ partial, int dp, unsigned *bar, int max_spin)
-{
-    __shared__ float acc_lds[kSweptOwnersPerWG * kSweptRPO * 64 + 4];   // 128 KiB of accumulators (+ the XCD id)
-    const int q = threadIdx.x >> 4;          // owner slot in the workgroup
-    const int l = threadIdx.x & 15;          // lane in the quarter-wave
-    float *myacc = acc_lds + q * (kSweptRPO * 64) + l * 4;
-    if (threadIdx.x == 0)
-        reinterpret_cast<unsigned *>(acc_lds)[kSweptOwnersPerWG * kSweptRPO * 64] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-    __syncthreads();
-    unsigned *ctr = bar + reinterpret_cast<unsigned *>(acc_lds)[kSweptOwnersPerWG * kSweptRPO * 64] * 32;   // HW_REG_XCC_ID
-    const unsigned members = gridDim.x / kSweptGroups;
-    unsigned seq = 0;
-    for (int slice = 0; slice < n_slices; ++slice) {
-        const float *Es = E + slice * 64 + l * 4;
-        for (int round = 0; round < n_rounds; ++round) {
-            const int64_t owner = ((int64_t)round * gridDim.x + blockIdx.x) * kSweptOwnersPerWG + q;
-#pragma unroll
-            for (int r = 0; r < kSweptRPO; ++r) *reinterpret_cast<float4 *>(myacc + r * 64) = vzero4();
-            const int64_t beg = own_ptr[owner], end = own_ptr[owner + 1];
-            const int32_t *blk = own_blk + owner * (int64_t)n_blocks;
-            // chunks this WAVE walks: the longest of its four owners
-            int my_chunks = (int)((end - beg + 15) >> 4);
-            my_chunks = max(my_chunks, __shfl_xor(my_chunks, 16));
-            my_chunks = max(my_chunks, __shfl_xor(my_chunks, 32));
-            int cur = 0, b = 0;
-            int bend = n_blocks > 0 ? blk[0] : 0x7fffffff;     // end of block b in this owner's list (kept one block ahead)
-            float4 a = vzero4();
-            int idle_col = end > beg ? e_col[beg] : 0;
-            // software pipeline: entries two chunks ahead, gathers one chunk ahead of the accumulation
-            float4 xA[16], xB[16];
-            SweptEntries eA = swept_load_entries(e_col, e_val, e_row, beg, end, l, idle_col);
-            SweptEntries eB = swept_load_entries(e_col, e_val, e_row, beg + 16, end, l, idle_col);
-            swept_issue(xA, eA, l, Es, ldE);
-            for (int k = 0; k < my_chunks; k += 2) {
-                // ---- chunk k (set A): prefetch entries k+2, issue gathers k+1, accumulate k
-                SweptEntries eC = swept_load_entries(e_col, e_val, e_row, beg + (int64_t)(k + 2) * 16, end, l, idle_col);
-                swept_issue(xB, eB, l, Es, ldE);
-                swept_accumulate(xA, eA, myacc, cur, a);
-                // a column block is finished once every owner of the wave has walked past its end
-                while (b < n_blocks) {
-                    int done = bend <= (k + 1) * 16 ? 1 : 0;
-                    done &= __shfl_xor(done, 16);
-                    done &= __shfl_xor(done, 32);
-                    if (!done) break;
-                    swept_group_sync(ctr, members * (++seq), max_spin);
-                    ++b;
-                    bend = b < n_blocks ? blk[b] : 0x7fffffff;
+    unsigned *ctr = bar + xcc_id * 32;
+    const unsigned members = gridDim.x / 8;
+    const bool sync = lead >= 0;
+    int perm = lead;                            // this wave's copy of perm_lds
+    int step0 = 0;                              // sweep steps of the passes before this one
+    const unsigned ld_bytes = (unsigned)ldE * 4u;
+    for (int rp = 0; rp < n_rowpass; ++rp) {
+        const int64_t task = ((int64_t)rp * gridDim.x + blockIdx.x) * NW + wave;
+        const int64_t *tp = tptr + task * n_win;
+        const int64_t beg = tp[0], end = tp[n_win];
+        for (int slice = 0; slice < n_slices; ++slice, step0 += n_win) {
+            const char *Eb = reinterpret_cast<const char *>(E + slice * kSW + p * 4);
+            for (int i = lane; i < RW * kSW; i += 64) wacc[i] = 0.f;
+            int b = 0;
+            int64_t wend = tp[1], wend_next = n_win > 1 ? tp[2] : end;
+            auto arrive = [&](int s) {           // this wave has left sweep step s behind
+                if (sync && lane == 0) {
+                    const unsigned old = atomicAdd(&wg_cnt[s % kRing], 1u);
+                    if ((old + 1) % NW == 0)
+                        __hip_atomic_fetch_add(ctr + (s % kRing), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // ---- chunk k+1 (set B)
-                eA = swept_load_entries(e_col, e_val, e_row, beg + (int64_t)(k + 3) * 16, end, l, idle_col);
-                swept_issue(xA, eC, l, Es, ldE);
-                swept_accumulate(xB, eB, myacc, cur, a);
-                while (b < n_blocks) {
-                    int done = bend <= (k + 2) * 16 ? 1 : 0;
-                    done &= __shfl_xor(done, 16);
-                    done &= __shfl_xor(done, 32);
-                    if (!done) break;
-                    swept_group_sync(ctr, members * (++seq), max_spin);
+            };
+            // windows left behind by a wave whose next slot is `pos`; then the permission to enter the new one
+            auto cross = [&](int64_t pos, bool crossed) {
+                while (b < n_win - 1 && pos >= wend) {
+                    arrive(step0 + b);
                     ++b;
-                    bend = b < n_blocks ? blk[b] : 0x7fffffff;
+                    wend = wend_next;
+                    wend_next = b + 2 <= n_win ? tp[b + 2] : end;
+                    crossed = true;
                 }
-                eB = eA;
-                eA = eC;
-                // rotate: next iteration accumulates chunk k+2 from xA (issued above from eC) with entries eA = eC,
-                // and needs eB = entries k+3
+                const int s = step0 + b;         // the step being entered needs step s-1-lead finished by the whole XCD
+                if (crossed && sync && max_spin > 0 && perm < s) {
+                    perm = __hip_atomic_load(&perm_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    int spins = 0;
+                    while (perm < s) {
+                        // lanes 0..kRing-1 read the ring; step t is finished when its slot reached members*(t/kRing+1)
+                        const unsigned mine = lane < kRing ? __hip_atomic_load(ctr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        int t = perm - lead;     // first step not yet known to be finished
+                        for (int k = 0; k < kRing - 2 - lead; ++k, ++t) {
+                            const unsigned have = __builtin_amdgcn_readlane(mine, t % kRing);
+                            if (have < members * (unsigned)(t / kRing + 1)) break;
+                        }
+                        perm = t + lead;         // steps <= perm may start
+                        if (perm >= s) break;
+                        if (++spins >= max_spin) {
+                            max_spin = 0;        // the XCD's workgroups are not resident together: stop waiting for good
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (lane == 0) atomicMax(&perm_lds, perm);
+                }
+            };
+            auto load_entries = [&](int64_t pos, int &pk, float &v) {
+                const int64_t idx = pos + held;
+                pk = INT32_MIN;
+                v = 0.f;
+                if (idx < end) {
+                    pk = e_pack[idx];
+                    v = e_val[idx];
+                }
+            };
+            if (end > beg) {
+                // empty slots gather the task's first row again (an L2 hit) and add nothing
+                const unsigned idle_off = (unsigned)(e_pack[beg] & kColMask) * ld_bytes;
+                int pkA, pkB;
+                float vA, vB;
+                f32x4 xa[8], xb[8];
+                unsigned offA;
+#define NGCF_GATHER(buf, u, j) buf[j] = *reinterpret_cast<const f32x4 *>(Eb + (unsigned)row_bcast<u>((int)offA));
+#define NGCF_GATHER_LO(x) NGCF_GATHER(x, 0, 0) NGCF_GATHER(x, 1, 1) NGCF_GATHER(x, 2, 2) NGCF_GATHER(x, 3, 3) NGCF_GATHER(x, 4, 4) NGCF_GATHER(x, 5, 5) NGCF_GATHER(x, 6, 6) NGCF_GATHER(x, 7, 7)
+#define NGCF_GATHER_HI(x) NGCF_GATHER(x, 8, 0) NGCF_GATHER(x, 9, 1) NGCF_GATHER(x, 10, 2) NGCF_GATHER(x, 11, 3) NGCF_GATHER(x, 12, 4) NGCF_GATHER(x, 13, 5) NGCF_GATHER(x, 14, 6) NGCF_GATHER(x, 15, 7)
+#define NGCF_ACC(buf, u, j)                                                                        \
+    {                                                                                             \
+        const int pku = row_bcast<u>(pkA);                                                        \
+        const float vu = row_bcast<u>(vA);                                                        \
+        if (pku >= 0) {                                                                           \
+            f32x4 *a = reinterpret_cast<f32x4 *>(wacc + (pku >> kRowBits) * kSW + p * 4);         \
+            f32x4 t = *a;                                                                         \
+            t.x = fmaf(vu, buf[j].x, t.x);                                                          \
+            t.y = fmaf(vu, buf[j].y, t.y);                                                          \
+            t.z = fmaf(vu, buf[j].z, t.z);                                                          \
+            t.w = fmaf(vu, buf[j].w, t.w);                                                          \
+            *a = t;                                                                               \
+        }                                                                                         \
+    }
+#define NGCF_ACC_LO(x) NGCF_ACC(x, 0, 0) NGCF_ACC(x, 1, 1) NGCF_ACC(x, 2, 2) NGCF_ACC(x, 3, 3) NGCF_ACC(x, 4, 4) NGCF_ACC(x, 5, 5) NGCF_ACC(x, 6, 6) NGCF_ACC(x, 7, 7)
+#define NGCF_ACC_HI(x) NGCF_ACC(x, 8, 0) NGCF_ACC(x, 9, 1) NGCF_ACC(x, 10, 2) NGCF_ACC(x, 11, 3) NGCF_ACC(x, 12, 4) NGCF_ACC(x, 13, 5) NGCF_ACC(x, 14, 6) NGCF_ACC(x, 15, 7)
+                load_entries(beg, pkA, vA);
+                cross(beg, true);
+                offA = pkA < 0 ? idle_off : (unsigned)(pkA & kColMask) * ld_bytes;
+                NGCF_GATHER_LO(xa)
+                for (int64_t pos = beg; pos < end; pos += kCH) {
+                    load_entries(pos + kCH, pkB, vB);                // the next chunk's entries, two gathers ahead
+                    const bool hi = pos + 8 * kEPR < end;
+                    if (hi) { NGCF_GATHER_HI(xb) }
+                    NGCF_ACC_LO(xa)
+                    if (pos + kCH < end) {
+                        cross(pos + kCH, false);
+                        offA = pkB < 0 ? idle_off : (unsigned)(pkB & kColMask) * ld_bytes;
+                        NGCF_GATHER_LO(xa)                           // first half of the next chunk, in flight during the adds below
+                    }
+                    if (hi) { NGCF_ACC_HI(xb) }
+                    pkA = pkB;
+                    vA = vB;
+                }
+#undef NGCF_GATHER
+#undef NGCF_GATHER_LO
+#undef NGCF_GATHER_HI
+#undef NGCF_ACC
+#undef NGCF_ACC_LO
+#undef NGCF_ACC_HI
             }
-            for (; b < n_blocks; ++b) swept_group_sync(ctr, members * (++seq), max_spin);   // every wave meets n_blocks times
-            swept_flush(myacc + cur * 64, a);
-            // write the owner's rows (its own LDS rows only: no barrier needed)
-#pragma unroll 1
-            for (int r = 0; r < kSweptRPO; ++r) {
-                const int64_t dst = own_dst[owner * kSweptRPO + r];
-                if (dst == kSweptUnused) continue;
-                float *p = dst >= 0 ? out + dst * ldo : partial + (-1 - dst) * (int64_t)dp;
-                *reinterpret_cast<float4 *>(p + slice * 64 + l * 4) = *reinterpret_cast<const float4 *>(myacc + r * 64);
+            cross(INT64_MAX - 1, false);         // leave the remaining windows (b ends at n_win-1) ...
+            arrive(step0 + n_win - 1);           // ... and the last one
+            // write this wave's rows (its own LDS rows; a wave's LDS operations complete in order)
+            for (int r0 = 0; r0 < RW; r0 += kEPR) {
+                const int r = r0 + g;
+                if (r < RW) {
+                    const int drow = dst[task * RW + r];
+                    if (drow != -1) {
+                        float *o = drow >= 0 ? out + (int64_t)drow * ldo : partial + (int64_t)(-2 - drow) * dp;
+                        *reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4) = *reinterpret_cast<const f32x4 *>(wacc + r * kSW + p * 4);
+                    }
+                }
             }
         }
     }
 }
 
-
+// kernels + fix-ups of every part; `partial` = workspace base (rows of dp floats)
 int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, float *partial, int dp,
                  hipStream_t stream)
 {
     const ngcf_csr::Swept &w = c->swept;
-    static const int max_spin = getenv("NGCF_SWEPT_SPIN") ? atoi(getenv("NGCF_SWEPT_SPIN")) : 400;
-    HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * kSweptGroups, stream));
-    prof_mark(stream, 0);
-    spmm_swept_kernel<<<dim3(kSweptWGs), NGCF_SWEPT_THREADS, 0, stream>>>(
-        w.own_ptr, w.own_blk, w.e_col, w.e_val, w.e_row, w.own_dst, w.n_rounds, w.n_blocks, d / 64, E, ldE, out, ldo, partial,
-        dp, w.barrier, max_spin);
-    LAUNCH_CHECK();
-    prof_mark(stream, 1);
-    if (w.n_heavy > 0) {
-        spmm_fixup_kernel<4><<<dim3((unsigned)((w.n_heavy + 3) / 4)), 256, 0, stream>>>(w.heavy_row, w.heavy_seg_ptr, w.n_heavy,
-                                                                                        partial, dp, d, out, ldo);
+    static const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);
+    static const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);
+    for (const auto &p : w.parts) {
+        float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
+        HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
+        if (p.waves == 16)
+            spmm_swept_kernel<kLdsRows / 16, 16><<<dim3(kSweptWGs), 16 * 64, 0, stream>>>(
+                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead);
+        else
+            spmm_swept_kernel<kLdsRows / 8, 8><<<dim3(kSweptWGs), 8 * 64, 0, stream>>>(
+                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead);
+        LAUNCH_CHECK();
+    }
+    for (const auto &p : w.parts) {
+        if (p.n_heavy == 0) continue;
+        spmm_fixup_kernel<4><<<dim3((unsigned)((p.n_heavy + 3) / 4)), 256, 0, stream>>>(
+            p.heavy_row, p.heavy_seg_ptr, p.n_heavy, partial + p.partial_base * (int64_t)dp, dp, d, out, ldo);
         LAUNCH_CHECK();
     }
     return NGCF_OK;

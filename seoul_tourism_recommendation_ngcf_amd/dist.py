@@ -25,6 +25,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -159,6 +161,10 @@ class ShardedPropagation:
             ir, ic, iv = rows[n_user_entries:] - U, cols[n_user_entries:], vals[n_user_entries:]
             sel = (ic >= lo) & (ic < hi)
             self.csr_it = _eng.LaplacianCSR.from_coo(ir[sel], ic[sel] - lo, iv[sel], I, max(self.nu, 1))
+            # the item partial sums run alone on the GPU (the all-reduce starts after them): L2-swept kernel where it
+            # pays.  The user rows overlap with the all-reduce; a persistent one-workgroup-per-CU kernel must not
+            # share the CUs with the collective's kernels, so they stay on the row-wise kernels.
+            self.csr_it.set_mode(int(os.environ.get("NGCF_SPMM_MODE", "3")))
             self.local_nnz = self.csr_u.nnz + self.csr_it.nnz
         else:
             cnt = row_counts(rows, self.N)

@@ -109,12 +109,18 @@ class LaplacianCSR:
         _lib.check(_lib.load().ngcf_csr_plan(self._h, int(seg_len), _stream()))
 
     def set_mode(self, mode: int):
-        """0 automatic, 1 row-wise gather kernel only, 2 L2-swept kernel whenever the width is a multiple of 64."""
+        """0 row-wise kernels (d-sliced where it pays), 1 row-wise without slicing, 2 L2-swept kernel wherever the shape
+        allows (tests), 3 L2-swept kernel on the row groups where it is expected to pay (long-lived matrices)."""
         _lib.check(_lib.load().ngcf_csr_set_mode(self._h, int(mode), _stream()))
 
     @property
     def n_segments(self) -> int:
         return int(_lib.load().ngcf_csr_n_segments(self._h))
+
+    @property
+    def swept_rows(self) -> int:
+        """Rows covered by L2-swept parts (0: all products of this CSR use the row-wise kernels)."""
+        return int(_lib.load().ngcf_csr_swept_rows(self._h))
 
     def layer_workspace_bytes(self, d_in: int, d_out: int) -> int:
         n = int(_lib.load().ngcf_layer_workspace_bytes(self._h, d_in, d_out))

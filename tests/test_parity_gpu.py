@@ -157,15 +157,26 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
         np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
         assert np.all(got[[0, 1, 500]] == 0)                      # empty rows are written as zeros
     if d % 64 == 0:
-        # the experimental L2-swept kernel (opt-in); rows longer than the per-owner budget are dealt to several
-        # pieces -> partial sums + fix-up
+        # the L2-swept kernel, forced onto this small matrix; rows longer than a quarter of a wave task's share are
+        # dealt to several pieces -> partial sums + fix-up
+        csr.set_mode(3)
+        assert csr.swept_rows == 0                                # mode 3: too small to pay, stays row-wise
         csr.set_mode(2)
+        assert csr.swept_rows == n_rows
         got = eng.spmm(csr, Ed).detach().cpu().numpy()
         np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
         assert np.all(got[[0, 1, 500]] == 0)
         got2 = eng.spmm(csr, Ed).detach().cpu().numpy()
         assert np.array_equal(got, got2)                          # deterministic: fixed summation order
+        big = torch.zeros((n_cols, d + 24), device=dev)           # strided operand through the swept kernel
+        big[:, 8:8 + d] = Ed
+        got3 = eng.spmm(csr, big[:, 8:8 + d]).detach().cpu().numpy()
+        assert np.array_equal(got, got3)
+        csr.plan(64)                                              # re-planning keeps the mode and rebuilds the parts
+        assert csr.swept_rows == n_rows
+        np.testing.assert_allclose(eng.spmm(csr, Ed).detach().cpu().numpy(), want, atol=ATOL, rtol=RTOL)
         csr.set_mode(1)
+        assert csr.swept_rows == 0
     # a column-sliced (strided) operand, as the engine uses for all_E blocks
     big = torch.zeros((n_cols, d + 24), device=dev)
     big[:, 8:8 + d] = Ed
@@ -175,8 +186,8 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
 
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
-    """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the opt-in
-    swept kernel and the plain row-wise kernel must give the same product."""
+    """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the L2-swept
+    kernel (forced) and the plain row-wise kernel must give the same product."""
     pkg = _pkg()
     eng = pkg.engine
     coo = pkg.graphs.synthetic_bipartite(150000, 12000, 2600000, seed=33, device=dev)
@@ -191,11 +202,44 @@ def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
     scale = float(rowwise.abs().max())
     assert float((swept - rowwise).abs().max()) <= 2e-6 * max(scale, 1.0)
     assert float((auto - rowwise).abs().max()) <= 2e-6 * max(scale, 1.0)
+    if d == 64:
+        # the swept kernel gathers with 32-bit byte offsets: a table spanning 2..4 GiB (offsets above 2^31) must
+        # still be addressed correctly, and one spanning more than 4 GiB must fall back to the row-wise kernels
+        csr.set_mode(2)
+        for ld in (3400, 6700):
+            wide = torch.zeros((N, ld), device=dev)
+            wide[:, 1000:1000 + d] = X
+            assert torch.equal(eng.spmm(csr, wide[:, 1000:1000 + d]), swept if ld == 3400 else auto)
+            del wide
+        csr.set_mode(1)
     rows = torch.cat([torch.randint(0, N, (64,), device=dev), torch.tensor([coo["n_user"], coo["n_user"] + 1], device=dev)])
     rp = torch.searchsorted(coo["rows"], torch.stack([rows, rows + 1]))
     for r, (lo, hi) in zip(rows.tolist(), rp.T.tolist()):
         want = (coo["vals"][lo:hi].double()[:, None] * X[coo["cols"][lo:hi]].double()).sum(0)
         np.testing.assert_allclose(swept[r].detach().cpu().numpy(), want.detach().cpu().numpy(), atol=ATOL, rtol=RTOL)
+
+
+def test_spmm_swept_many_rows_eight_wave_shape(dev):
+    """More than two row passes: the plan switches to 8 waves x 52 rows per workgroup.  Also a group with a handful
+    of very long rows (cut into strided pieces) and duplicate entries inside a row."""
+    pkg = _pkg()
+    eng = pkg.engine
+    coo = pkg.graphs.synthetic_bipartite(330000, 3000, 2000000, seed=35, device=dev)
+    N = coo["n_user"] + coo["n_item"]
+    rows, cols, vals = coo["rows"], coo["cols"], coo["vals"]
+    dup = torch.arange(0, rows.numel(), 1000, device=dev)         # every 1000th entry stored twice
+    rows, cols, vals = torch.cat([rows, rows[dup]]), torch.cat([cols, cols[dup]]), torch.cat([vals, vals[dup]])
+    order = torch.sort(rows, stable=True).indices
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    csr = eng.LaplacianCSR.from_coo(rows, cols, vals, N, N)
+    X = torch.randn((N, 64), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+    rowwise = eng.spmm(csr, X)
+    csr.set_mode(2)
+    assert csr.swept_rows == N
+    swept = eng.spmm(csr, X)
+    scale = float(rowwise.abs().max())
+    assert float((swept - rowwise).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert torch.equal(swept, eng.spmm(csr, X))
 
 
 def test_spmm_unsorted_and_duplicate_coo(dev, oracle_clib):
