@@ -30,9 +30,9 @@ constexpr int kEPR = 64 / kLPE;           // entries per round
 constexpr int kCH = 16 * kEPR;            // entries per chunk (16 rounds)
 constexpr int kSweptWGs = 256;            // one workgroup per CU
 constexpr int kRing = 8;                  // rotating sweep counters per XCD
-constexpr int kRowBits = 25;              // e_pack: column in bits 0..24, local row in bits 25..30, bit 31 = empty slot
+constexpr int kRowBits = 24;              // e_pack: column in bits 0..23, local row in bits 24..30
 constexpr int kColMask = (1 << kRowBits) - 1;
-constexpr int kLdsRows = 26 * 16;         // accumulator rows per workgroup (104 KiB of LDS)
+constexpr int kLdsRows = 36 * 16;         // accumulator rows per workgroup (144 KiB of LDS, + one spare row per wave)
 
 int env_int(const char *name, int dflt)
 {
@@ -212,7 +212,8 @@ int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hi
     });
     for (size_t i = 1; i < tptr.size(); ++i) tptr[i] += tptr[i - 1];
     const int64_t n_slots = tptr.back();
-    std::vector<int32_t> e_pack((size_t)std::max<int64_t>(n_slots, 1), INT32_MIN);
+    // empty slots add 0 x (a row of their own window, an L2 hit) to the wave's spare accumulator row RW
+    std::vector<int32_t> e_pack((size_t)std::max<int64_t>(n_slots, 1), -1);
     std::vector<float> e_val((size_t)std::max<int64_t>(n_slots, 1), 0.f);
     parallel_for(n_tasks, [&](int64_t lo, int64_t hi) {
         std::vector<int32_t> hist((size_t)n_win * RW);
@@ -239,6 +240,13 @@ int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hi
                     e_pack[(size_t)pos] = (int32_t)((uint32_t)lr << kRowBits) | col[(size_t)x];
                     e_val[(size_t)pos] = val[(size_t)x];
                 }
+            }
+            for (int64_t w = 0; w < n_win; ++w) {
+                const int64_t b0 = tptr[(size_t)(t * n_win + w)], b1 = tptr[(size_t)(t * n_win + w) + 1];
+                if (b0 == b1) continue;
+                const int32_t spare = (int32_t)((uint32_t)RW << kRowBits) | (e_pack[(size_t)b0] & kColMask);   // slot 0 is never empty
+                for (int64_t x = b0; x < b1; ++x)
+                    if (e_pack[(size_t)x] < 0) e_pack[(size_t)x] = spare;
             }
         }
     });
@@ -388,14 +396,14 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                                                              int64_t ldE, float *__restrict__ out, int64_t ldo,
                                                              float *__restrict__ partial, int dp, unsigned *bar, int max_spin, int lead)
 {
-    __shared__ float acc_lds[NW * RW * kSW];
+    __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];
     __shared__ int perm_lds;                    // highest sweep step this workgroup knows to be permitted
     __shared__ unsigned xcc_id;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, p = lane & 15;     // entry slot in the round, position in the slice
     const int held = p * kEPR + g;              // chunk entry this lane keeps: round u = lane u of every 16-lane row
-    float *wacc = acc_lds + wave * (RW * kSW);
+    float *wacc = acc_lds + wave * ((RW + 1) * kSW);
     if (threadIdx.x < kRing) wg_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID
@@ -413,8 +421,8 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
         const int64_t *tp = tptr + task * n_win;
         const int64_t beg = tp[0], end = tp[n_win];
         for (int slice = 0; slice < n_slices; ++slice, step0 += n_win) {
-            const char *Eb = reinterpret_cast<const char *>(E + slice * kSW + p * 4);
-            for (int i = lane; i < RW * kSW; i += 64) wacc[i] = 0.f;
+            const char *Eb = reinterpret_cast<const char *>(E + slice * kSW);   // uniform base + 32-bit lane offsets
+            for (int i = lane; i < (RW + 1) * kSW; i += 64) wacc[i] = 0.f;
             int b = 0;
             int64_t wend = tp[1], wend_next = n_win > 1 ? tp[2] : end;
             auto arrive = [&](int s) {           // this wave has left sweep step s behind
@@ -456,9 +464,10 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                     if (lane == 0) atomicMax(&perm_lds, perm);
                 }
             };
+            const int idle_pk = end > beg ? (RW << kRowBits) | (e_pack[beg] & kColMask) : 0;   // past the end: like an empty slot
             auto load_entries = [&](int64_t pos, int &pk, float &v) {
                 const int64_t idx = pos + held;
-                pk = INT32_MIN;
+                pk = idle_pk;
                 v = 0.f;
                 if (idx < end) {
                     pk = e_pack[idx];
@@ -466,13 +475,12 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                 }
             };
             if (end > beg) {
-                // empty slots gather the task's first row again (an L2 hit) and add nothing
-                const unsigned idle_off = (unsigned)(e_pack[beg] & kColMask) * ld_bytes;
                 int pkA, pkB;
                 float vA, vB;
                 f32x4 xa[8], xb[8];
                 unsigned offA;
-#define NGCF_GATHER(buf, u, j) buf[j] = *reinterpret_cast<const f32x4 *>(Eb + (unsigned)row_bcast<u>((int)offA));
+                const unsigned lane_off = p * 16;
+#define NGCF_GATHER(buf, u, j) buf[j] = *reinterpret_cast<const f32x4 *>(Eb + ((unsigned)row_bcast<u>((int)offA) + lane_off));
 #define NGCF_GATHER_LO(x) NGCF_GATHER(x, 0, 0) NGCF_GATHER(x, 1, 1) NGCF_GATHER(x, 2, 2) NGCF_GATHER(x, 3, 3) NGCF_GATHER(x, 4, 4) NGCF_GATHER(x, 5, 5) NGCF_GATHER(x, 6, 6) NGCF_GATHER(x, 7, 7)
 #define NGCF_GATHER_HI(x) NGCF_GATHER(x, 8, 0) NGCF_GATHER(x, 9, 1) NGCF_GATHER(x, 10, 2) NGCF_GATHER(x, 11, 3) NGCF_GATHER(x, 12, 4) NGCF_GATHER(x, 13, 5) NGCF_GATHER(x, 14, 6) NGCF_GATHER(x, 15, 7)
 #define NGCF_ACC(buf, u, j)                                                                        \
@@ -493,16 +501,19 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
 #define NGCF_ACC_HI(x) NGCF_ACC(x, 8, 0) NGCF_ACC(x, 9, 1) NGCF_ACC(x, 10, 2) NGCF_ACC(x, 11, 3) NGCF_ACC(x, 12, 4) NGCF_ACC(x, 13, 5) NGCF_ACC(x, 14, 6) NGCF_ACC(x, 15, 7)
                 load_entries(beg, pkA, vA);
                 cross(beg, true);
-                offA = pkA < 0 ? idle_off : (unsigned)(pkA & kColMask) * ld_bytes;
+                offA = (unsigned)(pkA & kColMask) * ld_bytes;
                 NGCF_GATHER_LO(xa)
                 for (int64_t pos = beg; pos < end; pos += kCH) {
                     load_entries(pos + kCH, pkB, vB);                // the next chunk's entries, two gathers ahead
                     const bool hi = pos + 8 * kEPR < end;
-                    if (hi) { NGCF_GATHER_HI(xb) }
+                    if (hi) {
+                        cross(pos + 8 * kEPR, false);                // no gather is issued into a window before its permission
+                        NGCF_GATHER_HI(xb)
+                    }
                     NGCF_ACC_LO(xa)
                     if (pos + kCH < end) {
                         cross(pos + kCH, false);
-                        offA = pkB < 0 ? idle_off : (unsigned)(pkB & kColMask) * ld_bytes;
+                        offA = (unsigned)(pkB & kColMask) * ld_bytes;
                         NGCF_GATHER_LO(xa)                           // first half of the next chunk, in flight during the adds below
                     }
                     if (hi) { NGCF_ACC_HI(xb) }
@@ -538,8 +549,8 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
                  hipStream_t stream)
 {
     const ngcf_csr::Swept &w = c->swept;
-    static const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);
-    static const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);
+    const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);                       // polls before a wave stops waiting for good
+    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);        // windows a wave may run ahead (-1: no sync)
     for (const auto &p : w.parts) {
         float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));

@@ -1,4 +1,5 @@
-"""Times the row-wise vs the L2-swept SpMM on the two halves of the C3 graph, sweeping the column-block size."""
+"""Times the row-wise / d-sliced kernels against the L2-swept kernel on the two halves of the C3 graph, sweeping the
+column-window size (plan time) and the allowed lead (launch time)."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +15,8 @@ nu = int(torch.searchsorted(rows, torch.tensor([U], device=dev)))
 parts = {"user rows": (rows[:nu], cols[:nu], vals[:nu], U), "item rows": (rows[nu:] - U, cols[nu:], vals[nu:], I)}
 E = torch.randn((N, d), device=dev)
 ws = eng.Workspace()
-blocks = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "256,512,1024,2048".split(","))]
+windows = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "2048,3072,4096,6144".split(","))]
+leads = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2".split(","))]
 
 
 def timeit(fn, n=5):
@@ -32,18 +34,21 @@ def timeit(fn, n=5):
 
 for name, (r, c, v, nr) in parts.items():
     csr = eng.LaplacianCSR.from_coo(r, c, v, nr, N)
-    csr.set_mode(1)
     out = torch.empty((nr, d), device=dev)
-    ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
+    for mode, label in ((1, "row-wise"), (0, "row-wise/d-sliced")):
+        csr.set_mode(mode)
+        ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
+        print(f"{name}: {label:18s} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s", flush=True)
     ref = out.clone()
-    print(f"{name}: row-wise            {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s", flush=True)
-    for kb in blocks:
-        os.environ["NGCF_SWEPT_BLOCK_KB"] = str(kb)
+    for kb in windows:
+        os.environ["NGCF_SWEPT_WINDOW_KB"] = str(kb)
         csr.set_mode(1)
         t0 = time.time()
         csr.set_mode(2)
         tb = time.time() - t0
-        ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
-        err = float((out - ref).abs().max())
-        print(f"{name}: swept block {kb:5d} KiB {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
-              f"(plan {tb:.1f} s, max diff {err:.1e})", flush=True)
+        for lead in leads:
+            os.environ["NGCF_SWEPT_LEAD"] = str(lead)
+            ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
+            err = float((out - ref).abs().max())
+            print(f"{name}: swept window {kb:5d} KiB lead {lead:2d} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
+                  f"(plan {tb:.1f} s, max diff {err:.1e})", flush=True)
