@@ -18,6 +18,23 @@ from . import engine as _eng
 from .engine import _ptr, _row_major_ld, _stream
 
 
+def _first_layer_input(owner, user_w, item_w, all_E, U, d0):
+    """E0 as the first layer reads it.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130,
+    515), so D is usually not a multiple of 4 and the rows of all_E are not 16-byte aligned; the first layer then
+    reads a copy whose rows are padded to a multiple of 4 floats, which lets the SpMM run its wide panel on the
+    float4 / L2-swept kernels (csrc/spmm.hip, spmm_dispatch) instead of scalar loads."""
+    if all_E.shape[1] % 4 == 0 and d0 % 4 == 0:
+        return all_E[:, :d0]
+    N, d0p = all_E.shape[0], (d0 + 3) // 4 * 4
+    pad = getattr(owner, "_e0_pad", None)
+    if pad is None or pad.device != all_E.device or tuple(pad.shape) != (N, d0p):
+        pad = torch.zeros((N, d0p), dtype=torch.float32, device=all_E.device)
+        owner._e0_pad = pad
+    _eng.copy_rows(user_w.detach(), pad[:U, :d0])
+    _eng.copy_rows(item_w.detach(), pad[U:, :d0])
+    return pad[:, :d0]
+
+
 def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.Tensor, item_w: torch.Tensor,
                       w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int], edge_drops=None):
     """all_E [N, D] = [E0 | norm(E1) | ... | norm(En)] (NGCF.py:120-147), inference path.
@@ -36,7 +53,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
     all_E = torch.empty((N, D), dtype=torch.float32, device=dev)
     _eng.copy_rows(user_w.detach(), all_E[:U, :d0])
     _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
-    prev = all_E[:, :d0]
+    prev = _first_layer_input(owner, user_w, item_w, all_E, U, d0)
     off = d0
     for k in range(n_layer):
         d_out = widths[k + 1]
@@ -116,7 +133,7 @@ class Propagate(torch.autograd.Function):
         all_E = torch.empty((N, sum(widths)), dtype=torch.float32, device=dev)
         _eng.copy_rows(user_w.detach(), all_E[:U, :d0])
         _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
-        prev = all_E[:, :d0]
+        prev = _first_layer_input(owner, user_w, item_w, all_E, U, d0)
         off = d0
         ins, les, carries = [], [], []
         for k in range(n_layer):

@@ -167,8 +167,8 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
     d = int(E.shape[1])
     if E.shape[0] != csr.n_cols:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({csr.n_rows}x{csr.n_cols} and {tuple(E.shape)})")
-    if out is None:
-        out = torch.empty((csr.n_rows, d), dtype=torch.float32, device=E.device)
+    if out is None:     # rows padded to a multiple of 4 floats (16-byte aligned rows: the float4 kernels apply at any d)
+        out = torch.empty((csr.n_rows, (d + 3) // 4 * 4), dtype=torch.float32, device=E.device)[:, :d]
     ws = ws or Workspace()
     nb = csr.spmm_workspace_bytes(d)
     w = ws.get(nb, E.device)

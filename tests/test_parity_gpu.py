@@ -177,6 +177,16 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
         np.testing.assert_allclose(eng.spmm(csr, Ed).detach().cpu().numpy(), want, atol=ATOL, rtol=RTOL)
         csr.set_mode(1)
         assert csr.swept_rows == 0
+    if d % 4 != 0:
+        # 16-byte aligned rows at a width that is not a multiple of 4 (the padded first-layer input at embed_size 65 /
+        # 130): wide panel on the float4 kernels - or the swept kernel - plus a narrow scalar tail panel
+        pad = torch.zeros((n_cols, (d + 3) // 4 * 4 + 4), device=dev)
+        pad[:, :d] = Ed
+        for mode in (0, 2):
+            csr.set_mode(mode)
+            got = eng.spmm(csr, pad[:, :d]).detach().cpu().numpy()
+            np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
+        csr.set_mode(1)
     # a column-sliced (strided) operand, as the engine uses for all_E blocks
     big = torch.zeros((n_cols, d + 24), device=dev)
     big[:, 8:8 + d] = Ed
@@ -602,6 +612,7 @@ def test_full_size_c3_properties(dev):
     model = pkg.NGCF(128, [128, 128, 128], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 1024, dev).to(dev).eval()
     csr = model.laplacian_csr(0)
     assert csr.nnz == coo["nnz"] and csr.n_segments > 0
+    assert csr.swept_rows == N                  # at this size the cached Laplacian runs on the L2-swept kernel (mode 3)
     g = torch.Generator(device=dev).manual_seed(9)
     X = torch.randn((N, 128), generator=g, device=dev)
     Y = torch.randn((N, 128), generator=g, device=dev)
@@ -609,6 +620,11 @@ def test_full_size_c3_properties(dev):
     LZ = eng.spmm(csr, 3.0 * X + 0.25 * Y)
     scale = float(LX.abs().max())
     assert float((LZ - (3.0 * LX + 0.25 * LY)).abs().max()) <= 2e-5 * max(scale, 1.0)
+    csr.set_mode(0)                             # the row-wise / d-sliced kernels give the same product
+    assert csr.swept_rows == 0
+    assert float((eng.spmm(csr, X) - LX).abs().max()) <= 2e-6 * max(scale, 1.0)
+    csr.set_mode(3)
+    assert torch.equal(eng.spmm(csr, X), LX)    # rebuilt plan, same bits
     a, b = float((Y.double() * LX.double()).sum()), float((LY.double() * X.double()).sum())
     assert abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1.0) + 1e-2
     rows = torch.cat([torch.randint(0, N, (24,), device=dev), torch.tensor([U, U + 1, 0], device=dev)])

@@ -19,6 +19,20 @@ batch = dict(year=torch.full((B,), 18), u_id=torch.randint(0, U, (B,), generator
              day=torch.randint(0, 32, (B,), generator=g), dow=torch.randint(0, 7, (B,), generator=g),
              pos_item=torch.randint(0, I, (B,), generator=g), neg_item=torch.randint(0, I, (B,), generator=g))
 batch = {k: v.to(dev) for k, v in batch.items()}
+model.eval()
+for split in ("1", ""):
+    if split:
+        os.environ["NGCF_NO_PANEL_SPLIT"] = split
+    else:
+        os.environ.pop("NGCF_NO_PANEL_SPLIT")
+    with torch.no_grad():
+        for it in range(5):
+            if it == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            model(node_flag=False, **batch)
+        torch.cuda.synchronize()
+    print(f"inference forward at 130 -> [128,128,128] (reference-legal width), panel split {'off' if split else 'on'}: "
+          f"{(time.perf_counter() - t0) / 3 * 1e3:.1f} ms", flush=True)
 for mode, node_flag, train in (("eval-mode grads, no dropout", False, False), ("train mode, device node dropout + message dropout", True, True)):
     model.train(train)
     model.node_dropout_mode = "device"
