@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--seg-len", type=int, default=0, help="override the row-segment length (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-items", action="store_true", help="secondary line: no popularity skew")
+    ap.add_argument("--hipgraph", action="store_true", help="Seoul-sized workloads: replay the forward as a hipGraph")
     return ap.parse_args()
 
 
@@ -183,8 +184,15 @@ def main():
                  for k, c in (("age", 76), ("sex", 2), ("month", 13), ("day", 32), ("dow", 7))}
         year = torch.full((args.batch,), 18, device=dev)
 
+        if args.hipgraph:                             # the batch lives in the graph's static index buffers
+            fwd = pkg.GraphedForward(model, args.batch, 0)
+            fwd(year=year, u_id=u_id, pos_item=pos, neg_item=neg, node_flag=False, **feats)
+
         def step():                                   # the whole NGCF.forward incl. the feature injection, then BPR
-            u, p, n = model(year=year, u_id=u_id, pos_item=pos, neg_item=neg, node_flag=False, **feats)
+            if args.hipgraph:
+                u, p, n = fwd.replay()
+            else:
+                u, p, n = model(year=year, u_id=u_id, pos_item=pos, neg_item=neg, node_flag=False, **feats)
             return crit(u, p, n)
     elif world == 1:
         csr = model.laplacian_csr(0)
@@ -269,6 +277,7 @@ def main():
                                f"batch={args.batch}, seed={seed}" + (", uniform items" if args.uniform_items else ""),
                    "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
                    "d": d0, "n_layers": n_layer, "batch": args.batch,
+                   "hipgraph": bool(args.hipgraph),
                    "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, exchange={args.exchange}"},
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

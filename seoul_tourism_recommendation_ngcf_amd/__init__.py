@@ -6,6 +6,7 @@ Drop-in for the hot path of haesungpyun/seoul_tourism_recommendation_NGCF:
 """
 from .NGCF import NGCF
 from .bprloss import BPR
+from .graphed import GraphedForward
 from . import engine, graphs
 
-__all__ = ["NGCF", "BPR", "engine", "graphs"]
+__all__ = ["NGCF", "BPR", "GraphedForward", "engine", "graphs"]

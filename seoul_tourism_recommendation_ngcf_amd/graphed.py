@@ -1,0 +1,94 @@
+"""hipGraph replay of the inference forward (NGCF.py:102-156) for launch-bound graphs.
+
+On the Seoul-sized graph (5 940 nodes) one forward is ~25 kernel launches of a few microseconds
+each: the step is bound by launch and Python overhead, not by the GPU.  `GraphedForward` captures the device side
+of `NGCF.forward` - feature injection, propagation, the three row gathers - once into a hipGraph (through
+`torch.cuda.CUDAGraph`: the library launches on torch's current stream, so its kernels are captured like torch's
+own) and replays it per batch.  What stays outside the graph is what needs the host: choosing the year slice
+(`year.unique()[0] % 18`, NGCF.py:117 - fixed at capture) and raising for out-of-range ids (the status word is
+read after the replay).
+
+Opt-in, eval mode only (no dropout draws), fixed batch size.  The returned tensors and `model.all_users_emb /
+all_items_emb` are the graph's static buffers: valid until the next replay (the eager forward returns fresh ones).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import engine as _eng
+from .autograd import propagate_forward
+
+
+class GraphedForward:
+    def __init__(self, model, batch_size: int, year_idx: int = 0, with_neg: bool = True):
+        if model.training:
+            raise RuntimeError("GraphedForward captures the eval-mode forward: call model.eval() first")
+        if model.emb_size % 5 != 0:
+            raise RuntimeError("embed_size must be a multiple of 5 (NGCF.py:39-43,114)")
+        self.model, self.B, self.year_idx, self.with_neg = model, int(batch_size), int(year_idx), bool(with_neg)
+        dev = model._dev()
+        self.dev = dev
+        z = lambda: torch.zeros(self.B, dtype=torch.int64, device=dev)  # noqa: E731
+        self.inputs = {k: z() for k in ("u_id", "age", "sex", "month", "day", "dow", "pos_item", "neg_item")}
+        self.csr = model.laplacian_csr(self.year_idx)      # built (and planned) outside the capture
+        self.status = model._status_buf(dev)
+        # the weights the injection overwrites must look the same at capture time as before it
+        saved = model.user_embedding.weight.data[:1].clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up: every cached buffer exists before the capture
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+        torch.cuda.synchronize(dev)
+        model.user_embedding.weight.data[:1].copy_(saved)  # row 0 was injected with the all-zero warm-up batch
+        self.status.zero_()
+
+    def _body(self):
+        m, i = self.model, self.inputs
+        with torch.no_grad():
+            _eng.feature_inject(m.user_embedding.weight.data,
+                                (m.age_emb.weight.data, m.sex_emb.weight.data, m.month_emb.weight.data,
+                                 m.day_emb.weight.data, m.dow_emb.weight.data),
+                                (i["age"], i["sex"], i["month"], i["day"], i["dow"]), i["u_id"], m.emb_ratio,
+                                m._scratch_buf(self.dev), self.status)
+            w1, b1, w2, b2 = m._layer_params()
+            all_E = propagate_forward(m, [self.csr] * m.n_layer, m.user_embedding.weight, m.item_embedding.weight,
+                                      w1, b1, w2, b2, [0.0] * m.n_layer, [0] * m.n_layer)
+            users, items = all_E[:m.n_user], all_E[m.n_user:]
+            u = _eng.gather_rows(users, i["u_id"], self.status)
+            p = _eng.gather_rows(items, i["pos_item"], self.status)
+            n = _eng.gather_rows(items, i["neg_item"], self.status) if self.with_neg else torch.empty(0)
+        return all_E, u, p, n
+
+    def __call__(self, u_id, age, sex, month, day, dow, pos_item, neg_item=None, year=None, node_flag=False):
+        """Same arguments as `NGCF.forward` (keyword calls work); `year` is not inspected - the slice was fixed at
+        capture - and `node_flag` must be False."""
+        if node_flag:
+            raise RuntimeError("GraphedForward replays the node_flag=False forward")
+        given = dict(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item)
+        if self.with_neg:
+            given["neg_item"] = neg_item
+        for k, v in given.items():
+            if v is None or int(v.numel()) != self.B:
+                raise RuntimeError(f"GraphedForward was captured for batches of {self.B}: {k} has "
+                                   f"{0 if v is None else int(v.numel())} elements")
+            self.inputs[k].copy_(v, non_blocking=True)
+        return self.replay()
+
+    def replay(self):
+        """Replay on whatever `self.inputs[...]` (the graph's static int64 index buffers) hold: callers that write their
+        batches straight into those buffers save the eight small copies of `__call__`."""
+        self.graph.replay()
+        all_E, u, p, n = self.out
+        m = self.model
+        m._all_E = all_E
+        m.all_users_emb, m.all_items_emb = all_E[:m.n_user], all_E[m.n_user:]       # NGCF.py:148-149
+        if m.check_indices and int(self.status.item()) != 0:
+            self.status.zero_()
+            raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
+        return u, p, n
