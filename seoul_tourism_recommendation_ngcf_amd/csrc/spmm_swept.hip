@@ -120,9 +120,10 @@ int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hi
         col_hi = std::max(col_hi, col[(size_t)x]);
     }
     if (col_hi > kColMask) return NGCF_OK;                           // column does not fit the packed entry
-    // workgroup shape: many row passes mean short wave tasks, whose fixed cost halves with 8 longer-lived waves
+    // workgroup shape: 16 waves x 36 rows.  8 waves x 72 rows (longer wave tasks, fewer pollers) was measured equal
+    // on the 7-pass user rows of C3 and 20 % slower on the item rows; it stays reachable for experiments.
     const int64_t cap = (int64_t)kSweptWGs * kLdsRows;               // output rows resident in LDS at a time
-    const int waves = (n + cap - 1) / cap >= 3 ? 8 : 16;
+    const int waves = env_int("NGCF_SWEPT_WAVES", 16) == 8 ? 8 : 16;
     const int RW = kLdsRows / waves;
     const int64_t n_wave_slots = (int64_t)kSweptWGs * waves;
     if (!force) {

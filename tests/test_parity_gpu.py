@@ -229,9 +229,12 @@ def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
         np.testing.assert_allclose(swept[r].detach().cpu().numpy(), want.detach().cpu().numpy(), atol=ATOL, rtol=RTOL)
 
 
-def test_spmm_swept_many_rows_eight_wave_shape(dev):
-    """More than two row passes: the plan switches to 8 waves x 52 rows per workgroup.  Also a group with a handful
-    of very long rows (cut into strided pieces) and duplicate entries inside a row."""
+@pytest.mark.parametrize("waves", ["16", "8"])
+def test_spmm_swept_many_rows_several_row_passes(waves, dev, monkeypatch):
+    """More output rows than the chip's LDS holds at once: several row passes, in both workgroup shapes (16 waves x 36
+    rows, and the 8 x 72 variant behind NGCF_SWEPT_WAVES).  Also a group with a handful of very long rows (cut into
+    strided pieces) and duplicate entries inside a row."""
+    monkeypatch.setenv("NGCF_SWEPT_WAVES", waves)
     pkg = _pkg()
     eng = pkg.engine
     coo = pkg.graphs.synthetic_bipartite(330000, 3000, 2000000, seed=35, device=dev)
