@@ -120,10 +120,12 @@ int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hi
         col_hi = std::max(col_hi, col[(size_t)x]);
     }
     if (col_hi > kColMask) return NGCF_OK;                           // column does not fit the packed entry
-    // workgroup shape: 16 waves x 36 rows.  8 waves x 72 rows (longer wave tasks, fewer pollers) was measured equal
-    // on the 7-pass user rows of C3 and 20 % slower on the item rows; it stays reachable for experiments.
+    // workgroup shape: 16 waves x 36 rows, or 8 x 72 when the rows need three or more passes (short wave tasks).  On
+    // the 7-pass user rows of C3 both run in 2.0 ms but 8 waves fetch 30 % less (PMC: 5.8 vs 8.4 GB); on the one-pass
+    // item rows 8 waves are 20 % slower.  NGCF_SWEPT_WAVES overrides (experiments, tests).
     const int64_t cap = (int64_t)kSweptWGs * kLdsRows;               // output rows resident in LDS at a time
-    const int waves = env_int("NGCF_SWEPT_WAVES", 16) == 8 ? 8 : 16;
+    int waves = (n + cap - 1) / cap >= 3 ? 8 : 16;
+    if (env_int("NGCF_SWEPT_WAVES", 0) == 8 || env_int("NGCF_SWEPT_WAVES", 0) == 16) waves = env_int("NGCF_SWEPT_WAVES", 0);
     const int RW = kLdsRows / waves;
     const int64_t n_wave_slots = (int64_t)kSweptWGs * waves;
     if (!force) {
@@ -142,7 +144,7 @@ int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hi
     for (;; ++n_rowpass) {
         n_tasks = n_rowpass * n_wave_slots;
         T = std::max<int64_t>(64, (nnz + n_tasks - 1) / n_tasks);
-        const int64_t Tp = std::max<int64_t>(64, T / 4);            // rows are cut well below a task's share: tasks mix freely
+        const int64_t Tp = std::max<int64_t>(64, T / std::max(2, env_int("NGCF_SWEPT_CUT", 4)));   // rows are cut well below a task's share
         pieces.clear();
         heavy_row.clear();
         heavy_ptr.assign(1, 0);

@@ -232,7 +232,7 @@ def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
 @pytest.mark.parametrize("waves", ["16", "8"])
 def test_spmm_swept_many_rows_several_row_passes(waves, dev, monkeypatch):
     """More output rows than the chip's LDS holds at once: several row passes, in both workgroup shapes (16 waves x 36
-    rows, and the 8 x 72 variant behind NGCF_SWEPT_WAVES).  Also a group with a handful of very long rows (cut into
+    rows and 8 x 72; NGCF_SWEPT_WAVES forces one).  Also a group with a handful of very long rows (cut into
     strided pieces) and duplicate entries inside a row."""
     monkeypatch.setenv("NGCF_SWEPT_WAVES", waves)
     pkg = _pkg()

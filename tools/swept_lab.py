@@ -40,9 +40,11 @@ for name, (r, c, v, nr) in parts.items():
         ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
         print(f"{name}: {label:18s} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s", flush=True)
     ref = out.clone()
-    for kb, waves in [(k_, w_) for k_ in windows for w_ in (os.environ.get("LAB_WAVES", "0").split(","))]:
+    for kb, waves, cut in [(k_, w_, c_) for k_ in windows for w_ in (os.environ.get("LAB_WAVES", "16").split(","))
+                           for c_ in os.environ.get("LAB_CUT", "4").split(",")]:
         os.environ["NGCF_SWEPT_WINDOW_KB"] = str(kb)
         os.environ["NGCF_SWEPT_WAVES"] = waves
+        os.environ["NGCF_SWEPT_CUT"] = cut
         csr.set_mode(1)
         t0 = time.time()
         csr.set_mode(2)
@@ -51,5 +53,5 @@ for name, (r, c, v, nr) in parts.items():
             os.environ["NGCF_SWEPT_LEAD"] = str(lead)
             ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
             err = float((out - ref).abs().max())
-            print(f"{name}: swept window {kb:5d} KiB waves {waves:>2s} lead {lead:2d} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
+            print(f"{name}: swept window {kb:5d} KiB waves {waves:>2s} cut T/{cut} lead {lead:2d} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
                   f"(plan {tb:.1f} s, max diff {err:.1e})", flush=True)
