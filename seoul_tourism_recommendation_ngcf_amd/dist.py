@@ -178,6 +178,7 @@ class ShardedPropagation:
             self.nu, self.ni = lay.n_users_of(r), lay.n_items_of(r)
             self.csr_u = _eng.LaplacianCSR.from_coo(ur, uc, uv, self.nu, lay.P)
             self.csr_i = _eng.LaplacianCSR.from_coo(ir, ic, iv, self.ni, lay.P)
+            self.csr_i.set_mode(int(os.environ.get("NGCF_SPMM_MODE", "3")))   # runs with no collective in flight (see above)
             self.local_nnz = self.csr_u.nnz + self.csr_i.nnz
         self._bufs = {}
 
