@@ -101,6 +101,21 @@ def _sp_concat(LE, E):
     return SP
 
 
+def _bwd_weight(dM, LE, E, ws):
+    """gW [d_out, 2 d_in] = dM^T . [LE+E | LE*E] on the fp32 matrix cores (ngcf_layer_bwd_weight_f32)."""
+    lib = _lib.load()
+    n_rows, d_out = dM.shape
+    d_in = int(LE.shape[1])
+    gW = torch.empty((d_out, 2 * d_in), dtype=torch.float32, device=dM.device)
+    nb = int(lib.ngcf_bwd_weight_workspace_bytes())
+    w = ws.get(nb, dM.device)
+    with torch.cuda.device(dM.device):
+        _lib.check(lib.ngcf_layer_bwd_weight_f32(_ptr(dM), _row_major_ld(dM, "dM"), _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E),
+                                                 _row_major_ld(E, "E"), n_rows, d_in, d_out, _ptr(gW), _ptr(w), w.numel(),
+                                                 _stream()))
+    return gW
+
+
 def _bwd_combine(dSP, LE, E):
     lib = _lib.load()
     n_rows, d = LE.shape
@@ -172,12 +187,15 @@ class Propagate(torch.autograd.Function):
             E_k = all_E[:, :widths[0]] if k == 0 else carries[k - 1]
             LE_k, C_k = les[k], carries[k]
             dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k])
-            SP = _sp_concat(LE_k, E_k)
-            gW = dM.t().mm(SP)                                                   # library GEMM: [d_out, 2 d_in]
+            if d_in <= 128 and d_out <= 128:
+                gW = _bwd_weight(dM, LE_k, E_k, ws)                              # MFMA kernel, operand formed on the fly
+            else:
+                SP = _sp_concat(LE_k, E_k)
+                gW = dM.t().mm(SP)                                               # library GEMM: [d_out, 2 d_in]
+                del SP
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
             gb = dM.sum(0)
             gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
-            del SP
             dSP = dM.mm(torch.cat((w1[k], w2[k]), dim=1))                        # library GEMM: [N, 2 d_in]
             dLE, dE = _bwd_combine(dSP, LE_k, E_k)
             del dSP, dM

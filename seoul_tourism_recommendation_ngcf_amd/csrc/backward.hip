@@ -207,3 +207,144 @@ extern "C" int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int6
     return NGCF_OK;
 }
 
+
+// ---- weight gradients of a layer on the fp32 matrix cores --------------------------------------
+//   gW[o][c]        = sum_rows dM[row][o] * (LE + E)[row][c]     (d loss / d W1, NGCF.py:131-133)
+//   gW[o][d_in + c] = sum_rows dM[row][o] * (LE * E)[row][c]     (d loss / d W2, NGCF.py:135-136)
+// A [d_out x 2 d_in] result with the 1.1 M rows as the reduction dimension: a library GEMM picks a 32x32 macro
+// tile for this shape (2.3 ms at C3) and needs the [LE+E | LE*E] operand materialised (1.1 GB).  Here 256
+// persistent workgroups stream blocks of 32 rows through LDS (the sum/product operand is formed on the way in),
+// 8 waves each keep 4 of the 32 output tiles in registers (v_mfma_f32_32x32x2_f32: A = dM^T, B = [S|P], k = row),
+// and write one partial result per workgroup; a second kernel adds the partials in workgroup order (fixed order,
+// no atomics).  Widths up to 128 (padded to multiples of 32 inside LDS); wider layers use the library GEMM.
+typedef float bw_f32x16 __attribute__((ext_vector_type(16)));
+typedef float bw_f32x4 __attribute__((ext_vector_type(4)));
+static constexpr int kBwRows = 32;        // rows per LDS block
+static constexpr int kBwWGs = 256;
+static constexpr int kBwM = 128, kBwN = 256;
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict__ dM, int64_t ldM,
+                                                         const float *__restrict__ LE, int64_t ldLE,
+                                                         const float *__restrict__ E, int64_t ldE, int64_t n_rows, int d_in,
+                                                         int d_out, int P, float *__restrict__ partial)
+{
+    __shared__ float As[2][kBwRows][kBwM];     // dM rows, columns >= d_out stay zero
+    __shared__ float Bs[2][kBwRows][kBwN];     // [LE+E (P columns) | LE*E (P columns)], the rest stays zero
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    for (int i = tid; i < 2 * kBwRows * kBwM; i += 512) (&As[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * kBwRows * kBwN; i += 512) (&Bs[0][0][0])[i] = 0.f;
+    bw_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // staging: 2 float4 slots per thread and operand: slot s -> row s / 32, columns 4 * (s % 32) ..
+    bw_f32x4 rm[2], rl[2], re[2];
+    const int64_t n_blocks = (n_rows + kBwRows - 1) / kBwRows;
+    auto load4 = [&](const float *base, int64_t ld, int64_t row, int c, int width) -> bw_f32x4 {
+        bw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n_rows && c < width) {
+            const float *p = base + row * ld + c;
+            if (ALIGNED && c + 4 <= width) {
+                v = *reinterpret_cast<const bw_f32x4 *>(p);
+            } else {
+                v.x = p[0];
+                if (c + 1 < width) v.y = p[1];
+                if (c + 2 < width) v.z = p[2];
+                if (c + 3 < width) v.w = p[3];
+            }
+        }
+        return v;
+    };
+    auto load_block = [&](int64_t b) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int s = tid + s2 * 512, r = s >> 5, c = (s & 31) * 4;
+            const int64_t row = b * kBwRows + r;
+            rm[s2] = load4(dM, ldM, row, c, d_out);
+            rl[s2] = load4(LE, ldLE, row, c, d_in);
+            re[s2] = load4(E, ldE, row, c, d_in);
+        }
+    };
+    auto store_block = [&](int buf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int s = tid + s2 * 512, r = s >> 5, c = (s & 31) * 4;
+            *reinterpret_cast<bw_f32x4 *>(&As[buf][r][c]) = rm[s2];
+            if (c < P) {
+                *reinterpret_cast<bw_f32x4 *>(&Bs[buf][r][c]) = rl[s2] + re[s2];
+                *reinterpret_cast<bw_f32x4 *>(&Bs[buf][r][P + c]) = rl[s2] * re[s2];
+            }
+        }
+    };
+    __syncthreads();                           // LDS zeroed
+    int64_t b = blockIdx.x;
+    if (b < n_blocks) {
+        load_block(b);
+        store_block(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; b < n_blocks; b += gridDim.x, buf ^= 1) {
+        const bool more = b + gridDim.x < n_blocks;
+        if (more) load_block(b + gridDim.x);   // the next block's global loads fly under the MFMAs
+#pragma unroll
+        for (int j = 0; j < kBwRows / 2; ++j) {
+            const float bv = Bs[buf][2 * j + lh][wave * 32 + li];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * j + lh][t * 32 + li], bv, acc[t], 0, 0, 0);
+        }
+        if (more) store_block(buf ^ 1);
+        __syncthreads();
+    }
+    float *out = partial + (int64_t)blockIdx.x * kBwM * kBwN;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[o * kBwN + wave * 32 + li] = acc[t][r];
+        }
+}
+
+__global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, int n_wg, int d_in, int d_out, int P,
+                                         float *__restrict__ gW)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d_out * 2 * d_in) return;
+    const int o = i / (2 * d_in), c = i % (2 * d_in);
+    const int src = c < d_in ? c : P + (c - d_in);
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += partial[((int64_t)w * kBwM + o) * kBwN + src];
+    gW[i] = s;
+}
+
+extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void) { return (int64_t)kBwWGs * kBwM * kBwN * sizeof(float) + 256; }
+
+extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E,
+                                         int64_t ldE, int64_t n_rows, int d_in, int d_out, float *gW, void *workspace,
+                                         int64_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!gW || (n_rows > 0 && (!dM || !LE || !E))) return fail(NGCF_ERR_ARG, "layer_bwd_weight: null argument");
+    if (n_rows < 0 || d_in < 1 || d_out < 1 || d_in > 128 || d_out > 128)
+        return fail(NGCF_ERR_ARG, "layer_bwd_weight: widths d_in=%d d_out=%d not in 1..128", d_in, d_out);
+    if (ldM < d_out || ldLE < d_in || ldE < d_in) return fail(NGCF_ERR_ARG, "layer_bwd_weight: leading dimension too small");
+    if (!workspace || workspace_bytes < ngcf_bwd_weight_workspace_bytes())
+        return fail(NGCF_ERR_WORKSPACE, "layer_bwd_weight: workspace %lld B < %lld B", (long long)workspace_bytes,
+                    (long long)ngcf_bwd_weight_workspace_bytes());
+    float *partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    const int P = (int)align_up(d_in, 32);
+    const bool al = ldM % 4 == 0 && ldLE % 4 == 0 && ldE % 4 == 0 && aligned16(dM) && aligned16(LE) && aligned16(E);
+    if (al)
+        bwd_weight_kernel<true><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial);
+    else
+        bwd_weight_kernel<false><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial);
+    LAUNCH_CHECK();
+    const int total = d_out * 2 * d_in;
+    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, kBwWGs, d_in, d_out, P, gW);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}

@@ -136,3 +136,23 @@ def test_bpr_backward_matches_golden_grads(dev):
         for t, k in ((u, "gu"), (p, "gp"), (n, "gn")):
             want = 3.0 * g[f"{tag}_{k}"]
             np.testing.assert_allclose(t.grad.cpu().numpy(), want, atol=1e-7 + 1e-5 * np.abs(want).max(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(0, 16, 8, False), (33, 7, 5, False), (1000, 65, 64, False),
+                                                        (9001, 128, 128, False), (70000, 130 - 2, 96, True)])
+def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
+    """gW = dM^T . [LE+E | LE*E] (MFMA kernel, csrc/backward.hip) against fp64 from the definition (NGCF.py:131-136),
+    incl. widths that are not multiples of 32 or 4, a row count that is not a multiple of the block, strided operands
+    and the empty case.  Summation order differs from any reference GEMM: tolerance, relative to the result's scale."""
+    from seoul_tourism_recommendation_ngcf_amd import autograd, engine
+    g = torch.Generator(device=dev).manual_seed(n_rows + d_in)
+    mk = lambda n, d: torch.randn((n, d + (12 if strided else 0)), generator=g, device=dev)[:, :d]  # noqa: E731
+    dM, LE, E = mk(n_rows, d_out), mk(n_rows, d_in), mk(n_rows, d_in)
+    ws = engine.Workspace()
+    got = autograd._bwd_weight(dM, LE, E, ws)
+    assert got.shape == (d_out, 2 * d_in)
+    SP = torch.cat([LE.double() + E.double(), LE.double() * E.double()], 1)
+    want = dM.double().t() @ SP
+    scale = max(float(want.abs().max()), 1.0) if n_rows else 1.0
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale
+    assert torch.equal(got, autograd._bwd_weight(dM, LE, E, ws))        # fixed summation order
