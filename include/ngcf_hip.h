@@ -208,14 +208,14 @@ int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ld
 /* dSP[n_rows, 2d] = dM.[W1 | W2]  ->  dLE = dS + dP*E,  dE_direct = dS + dP*LE  (both [n_rows, d] contiguous). */
 /* weight gradients of one layer on the fp32 matrix cores: gW [d_out, 2 d_in] row-major,
  * gW[:, :d_in] = dM^T . (LE + E) (W1, NGCF.py:131-133), gW[:, d_in:] = dM^T . (LE * E) (W2, NGCF.py:135-136);
- * d_in, d_out <= 128 (wider layers: form the operand with ngcf_sp_concat_f32 and use a library GEMM).  Fixed
+ * d_in, d_out <= 128 per call (the host tiles wider layers over column blocks of dM, LE and E).  Fixed
  * summation order (per-workgroup partials in the workspace, added in workgroup order). */
 int64_t ngcf_bwd_weight_workspace_bytes(void);
 int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
                               int64_t n_rows, int d_in, int d_out, float *gW, void *workspace, int64_t workspace_bytes,
                               void *stream);
 int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
-                               int64_t n_rows, int d, float *dLE, float *dE, void *stream);
+                               int64_t n_rows, int d, float *dLE, int64_t ld_dLE, float *dE, int64_t ld_dE, void *stream);
 /* out[r, 0:d] += add[r, 0:d] */
 int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream);
 

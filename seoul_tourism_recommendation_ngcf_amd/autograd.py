@@ -102,7 +102,8 @@ def _sp_concat(LE, E):
 
 
 def _bwd_weight(dM, LE, E, ws):
-    """gW [d_out, 2 d_in] = dM^T . [LE+E | LE*E] on the fp32 matrix cores (ngcf_layer_bwd_weight_f32)."""
+    """gW [d_out, 2 d_in] = dM^T . [LE+E | LE*E] on the fp32 matrix cores (ngcf_layer_bwd_weight_f32), in blocks of
+    at most 128 output rows x 128 input columns (one kernel call each)."""
     lib = _lib.load()
     n_rows, d_out = dM.shape
     d_in = int(LE.shape[1])
@@ -110,20 +111,31 @@ def _bwd_weight(dM, LE, E, ws):
     nb = int(lib.ngcf_bwd_weight_workspace_bytes())
     w = ws.get(nb, dM.device)
     with torch.cuda.device(dM.device):
-        _lib.check(lib.ngcf_layer_bwd_weight_f32(_ptr(dM), _row_major_ld(dM, "dM"), _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E),
-                                                 _row_major_ld(E, "E"), n_rows, d_in, d_out, _ptr(gW), _ptr(w), w.numel(),
-                                                 _stream()))
+        for o0 in range(0, d_out, 128):
+            o1 = min(d_out, o0 + 128)
+            for c0 in range(0, d_in, 128):
+                c1 = min(d_in, c0 + 128)
+                whole = o0 == 0 and o1 == d_out and c0 == 0 and c1 == d_in
+                blk = gW if whole else torch.empty((o1 - o0, 2 * (c1 - c0)), dtype=torch.float32, device=dM.device)
+                a, b, c = dM[:, o0:o1], LE[:, c0:c1], E[:, c0:c1]
+                _lib.check(lib.ngcf_layer_bwd_weight_f32(_ptr(a), _row_major_ld(a, "dM"), _ptr(b), _row_major_ld(b, "LE"),
+                                                         _ptr(c), _row_major_ld(c, "E"), n_rows, c1 - c0, o1 - o0, _ptr(blk),
+                                                         _ptr(w), w.numel(), _stream()))
+                if not whole:
+                    gW[o0:o1, c0:c1] = blk[:, :c1 - c0]
+                    gW[o0:o1, d_in + c0:d_in + c1] = blk[:, c1 - c0:]
     return gW
 
 
 def _bwd_combine(dSP, LE, E):
     lib = _lib.load()
     n_rows, d = LE.shape
-    dLE = torch.empty((n_rows, d), dtype=torch.float32, device=LE.device)
-    dE = torch.empty((n_rows, d), dtype=torch.float32, device=LE.device)
+    d4 = (d + 3) // 4 * 4      # 16-byte aligned rows: L^T . dLE then runs on the float4 / swept kernels at any width
+    dLE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
+    dE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
     with torch.cuda.device(LE.device):
         _lib.check(lib.ngcf_layer_bwd_combine_f32(_ptr(dSP), _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E),
-                                                  _row_major_ld(E, "E"), n_rows, d, _ptr(dLE), _ptr(dE), _stream()))
+                                                  _row_major_ld(E, "E"), n_rows, d, _ptr(dLE), d4, _ptr(dE), d4, _stream()))
     return dLE, dE
 
 
@@ -187,12 +199,7 @@ class Propagate(torch.autograd.Function):
             E_k = all_E[:, :widths[0]] if k == 0 else carries[k - 1]
             LE_k, C_k = les[k], carries[k]
             dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k])
-            if d_in <= 128 and d_out <= 128:
-                gW = _bwd_weight(dM, LE_k, E_k, ws)                              # MFMA kernel, operand formed on the fly
-            else:
-                SP = _sp_concat(LE_k, E_k)
-                gW = dM.t().mm(SP)                                               # library GEMM: [d_out, 2 d_in]
-                del SP
+            gW = _bwd_weight(dM, LE_k, E_k, ws)                                  # MFMA kernel, operand formed on the fly
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
             gb = dM.sum(0)
             gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)

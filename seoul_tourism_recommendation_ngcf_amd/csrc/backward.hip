@@ -165,24 +165,26 @@ extern "C" int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E,
 // ---- dSP = dM.[W1 | W2] -> dLE = dS + dP*E ; dE_direct = dS + dP*LE ----------------------------
 __global__ void layer_bwd_combine_kernel(const float *__restrict__ dSP, const float *__restrict__ LE, int64_t ldLE,
                                          const float *__restrict__ E, int64_t ldE, int64_t n_rows, int d,
-                                         float *__restrict__ dLE, float *__restrict__ dE)
+                                         float *__restrict__ dLE, int64_t ldd, float *__restrict__ dE, int64_t lde)
 {
     const int64_t total = n_rows * d;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / d;
         const int j = (int)(i % d);
         const float ds = dSP[r * 2 * d + j], dp = dSP[r * 2 * d + d + j];
-        dLE[i] = fmaf(dp, E[r * ldE + j], ds);
-        dE[i] = fmaf(dp, LE[r * ldLE + j], ds);
+        dLE[r * ldd + j] = fmaf(dp, E[r * ldE + j], ds);
+        dE[r * lde + j] = fmaf(dp, LE[r * ldLE + j], ds);
     }
 }
 
 extern "C" int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
-                                          int64_t n_rows, int d, float *dLE, float *dE, void *stream_)
+                                          int64_t n_rows, int d, float *dLE, int64_t ldd, float *dE, int64_t lde,
+                                          void *stream_)
 {
     if (n_rows == 0) return NGCF_OK;
-    if (!dSP || !LE || !E || !dLE || !dE || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_combine: bad argument");
-    layer_bwd_combine_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(dSP, LE, ldLE, E, ldE, n_rows, d, dLE, dE);
+    if (!dSP || !LE || !E || !dLE || !dE || d <= 0 || ldd < d || lde < d) return fail(NGCF_ERR_ARG, "layer_bwd_combine: bad argument");
+    layer_bwd_combine_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(dSP, LE, ldLE, E, ldE, n_rows, d, dLE, ldd,
+                                                                                          dE, lde);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
