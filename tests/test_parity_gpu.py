@@ -255,6 +255,26 @@ def test_spmm_swept_many_rows_several_row_passes(waves, dev, monkeypatch):
     assert torch.equal(swept, eng.spmm(csr, X))
 
 
+@pytest.mark.parametrize("n_rows,n_cols,deg,heavy", [(1, 1, 1, ()), (5, 3, 40, ()), (2000, 70000, 1, ()),
+                                                      (300, 50000, 3, ((0, 120000), (299, 9000))), (40, 17, 0, ((7, 5000),))])
+def test_spmm_swept_degenerate_shapes(n_rows, n_cols, deg, heavy, dev, oracle_clib):
+    """The swept plan forced onto shapes it was not made for: one entry, a few columns with thousands of duplicates per
+    row (rounds = longest row), one entry per row over many windows, a row far longer than everything else together
+    (strided pieces + fix-up), everything in one row."""
+    eng = _pkg().engine
+    rng = np.random.default_rng(n_rows + n_cols)
+    rowptr, rows, cols, vals = random_csr(rng, n_rows, n_cols, deg, heavy=heavy)
+    E = rng.normal(0, 0.5, (n_cols, 64)).astype(np.float32)
+    want = c_spmm(oracle_clib, rowptr, cols.astype(np.int32), vals, E)
+    csr = eng.LaplacianCSR.from_coo(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev),
+                                    torch.from_numpy(vals).to(dev), n_rows, n_cols)
+    csr.set_mode(2)
+    assert csr.swept_rows == (n_rows if len(vals) else 0)
+    got = eng.spmm(csr, torch.from_numpy(E).to(dev)).detach().cpu().numpy()
+    scale = max(float(np.abs(want).max()), 1.0)
+    assert float(np.abs(got - want).max()) <= 2e-5 * scale           # long rows: summation order differs from the oracle's
+
+
 def test_spmm_unsorted_and_duplicate_coo(dev, oracle_clib):
     eng = _pkg().engine
     rng = np.random.default_rng(3)
