@@ -187,7 +187,7 @@ int ngcf_bpr_fused_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, c
                        int D, float weight_decay, float batch_size, float *loss,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
-/* ---- backward pass (experimental; `loss.backward()` of experiment.py:57) -------------------- */
+/* ---- backward pass (`loss.backward()` of experiment.py:57; driven by autograd.py) -------------- */
 /* The two plain GEMMs of a layer's backward (dM.[W1|W2] and dM^T.[S|P]) are library GEMMs issued by the host
  * mirror; the entry points below are everything around them.  L^T.dLE re-uses ngcf_spmm_csr_f32 on the CSR of L^T. */
 /* du/dp/dn of the BPR loss (bprloss.py:15-22) times the upstream scalar *grad_out (device). */
