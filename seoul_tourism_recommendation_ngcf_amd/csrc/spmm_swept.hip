@@ -318,6 +318,12 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     ngcf_csr::Swept &w = c->swept;
     w.built_mode = c->mode;
     if (c->mode < 2 || c->n_rows == 0 || c->nnz == 0) return NGCF_OK;
+    // the plan is laid out for one resident workgroup on each of 256 CUs in 8 XCDs (an MI355X in SPX mode); on any
+    // other partitioning the grid would not be resident together, so the products stay on the row-wise kernels
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus != kSweptWGs)
+        return NGCF_OK;
     w.group_swept.assign(c->groups.size(), 0);
     for (size_t g = 0; g < c->groups.size(); ++g) {
         ngcf_csr::Swept::Part p;
