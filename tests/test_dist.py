@@ -168,9 +168,13 @@ def test_layout_and_bounds_single_process():
 # ------------------------------------------------------------------------------------------------
 # GPU: the real sharded HIP path, two ranks on one device
 # ------------------------------------------------------------------------------------------------
-def _gpu_worker(rank, world, port, mode, ret):
+def _gpu_worker(rank, world, port, mode, ret, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import seoul_tourism_recommendation_ngcf_amd as pkg
         from seoul_tourism_recommendation_ngcf_amd import dist as nd
@@ -212,3 +216,14 @@ def test_sharded_propagation_ranks_share_one_gpu(mode, world):
         ret = mgr.dict()
         mp.spawn(_gpu_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bipartite", "allgather"])
+def test_sharded_propagation_one_rank_over_rccl(mode):
+    """The collectives of the sharded path issued through RCCL itself (backend "nccl"), with the one rank a one-GPU
+    box allows: communicator set-up, async work handles on device buffers, all_gather_into_tensor on views."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gpu_worker, args=(1, _free_port(), mode, ret, "nccl"), nprocs=1, join=True)
+        assert dict(ret) == {0: True}
