@@ -79,7 +79,7 @@ struct ngcf_csr {
     int32_t *heavy_row = nullptr;      // device [n_heavy] rows that were cut
     int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1] their segment ranges
     // row groups: maximal runs of rows whose gathered column range is small enough that d-slicing pays
-    struct RowGroup { int64_t begin, end; bool sliceable; };
+    struct RowGroup { int64_t begin, end; bool sliceable; int32_t col_lo, col_hi; };   // col_hi < col_lo: no entries
     std::vector<RowGroup> groups;
     // L2-swept plan (spmm_swept.hip): built on request (mode 2/3) for long-lived matrices
     int mode = 0;                      // 0 row-wise (+ d-sliced groups), 1 row-wise only, 2 swept wherever the shape

@@ -155,7 +155,7 @@ static int build_row_groups(ngcf_csr *c, hipStream_t stream)
         if (!c->groups.empty() && c->groups.back().sliceable == s)
             c->groups.back().end = hi;
         else
-            c->groups.push_back({lo, hi, s});
+            c->groups.push_back({lo, hi, s, INT32_MAX, -1});
     }
     // a group of a few blocks is not worth its own launch: give it its neighbour's class, then fuse equal neighbours
     for (size_t i = 0; i < c->groups.size(); ++i)
@@ -169,6 +169,12 @@ static int build_row_groups(ngcf_csr *c, hipStream_t stream)
             ++k;
         }
     }
+    for (auto &g : c->groups)                  // column range every group gathers from (the swept plan's first question)
+        for (int64_t b = g.begin / NGCF_GROUP_ROWS; b * NGCF_GROUP_ROWS < g.end; ++b)
+            if (h_max[(size_t)b] >= 0) {
+                g.col_lo = std::min(g.col_lo, h_min[(size_t)b]);
+                g.col_hi = std::max(g.col_hi, h_max[(size_t)b]);
+            }
     return NGCF_OK;
 }
 

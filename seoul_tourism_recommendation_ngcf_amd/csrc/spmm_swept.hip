@@ -98,28 +98,18 @@ struct Piece {
 
 // Plan of the rows [row_lo, row_hi).  Leaves part.waves == 0 when the part is not worth it (mode 3) or the shape does
 // not fit the entry encoding.
-int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hipStream_t stream, ngcf_csr::Swept::Part &part)
+int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hipStream_t stream, ngcf_csr::Swept::Part &part)
 {
-    const int64_t n = row_hi - row_lo;
-    if (n <= 0) return NGCF_OK;
+    const int64_t row_lo = grp.begin, row_hi = grp.end, n = row_hi - row_lo;
+    const int32_t col_lo = grp.col_lo, col_hi = grp.col_hi;
+    if (n <= 0 || col_hi < col_lo) return NGCF_OK;
+    if (col_hi > kColMask) return NGCF_OK;                           // column does not fit the packed entry
     std::vector<int64_t> rp((size_t)n + 1);
     HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr + row_lo, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const int64_t e0 = rp[0], nnz = rp[(size_t)n] - e0;
     if (nnz <= 0) return NGCF_OK;
     if (!force && nnz < ((int64_t)1 << 22)) return NGCF_OK;          // small products are launch-bound, not L2-bound
-    std::vector<int32_t> col((size_t)nnz);
-    std::vector<float> val((size_t)nnz);
-    HIP_TRY(hipMemcpyAsync(col.data(), c->colidx + e0, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(val.data(), c->vals + e0, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (auto &x : rp) x -= e0;
-    int32_t col_lo = INT32_MAX, col_hi = 0;
-    for (int64_t x = 0; x < nnz; ++x) {
-        col_lo = std::min(col_lo, col[(size_t)x]);
-        col_hi = std::max(col_hi, col[(size_t)x]);
-    }
-    if (col_hi > kColMask) return NGCF_OK;                           // column does not fit the packed entry
     // workgroup shape: 16 waves x 36 rows, or 8 x 72 when the rows need three or more passes (short wave tasks).  On
     // the 7-pass user rows of C3 both run in 2.0 ms but 8 waves fetch 30 % less (PMC: 5.8 vs 8.4 GB); on the one-pass
     // item rows 8 waves are 20 % slower.  NGCF_SWEPT_WAVES overrides (experiments, tests).
@@ -136,6 +126,12 @@ int build_part(const ngcf_csr *c, int64_t row_lo, int64_t row_hi, bool force, hi
         const double reuse = (double)nnz / span * std::min(1.0, (double)(cap / 8) / (double)n);
         if (reuse < 3.0 || span * kSW * 4 < (double)(8 << 20)) return NGCF_OK;
     }
+    std::vector<int32_t> col((size_t)nnz);    // only now the entries come to the host
+    std::vector<float> val((size_t)nnz);
+    HIP_TRY(hipMemcpyAsync(col.data(), c->colidx + e0, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(val.data(), c->vals + e0, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (auto &x : rp) x -= e0;
     // 1) pieces and wave tasks: all tasks get the same number of entries and at most RW rows
     int64_t n_rowpass = std::max<int64_t>(1, (n + cap - 1) / cap), n_tasks = 0, T = 0, n_partial = 0;
     std::vector<Piece> pieces;
@@ -327,7 +323,7 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     w.group_swept.assign(c->groups.size(), 0);
     for (size_t g = 0; g < c->groups.size(); ++g) {
         ngcf_csr::Swept::Part p;
-        const int rc = build_part(c, c->groups[g].begin, c->groups[g].end, c->mode == 2, stream, p);
+        const int rc = build_part(c, c->groups[g], c->mode == 2, stream, p);
         if (rc != NGCF_OK) {
             free_swept(c);
             return rc;
