@@ -177,7 +177,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
         }
     }
     // 2) column windows and the slot layout of every (task, window) bucket
-    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", 4096);
+    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", 2048);
     if (win_kb < 16) win_kb = 16;
     const int32_t win_cols = (int32_t)std::max<int64_t>(64, win_kb * 1024 / (kSW * 4));
     const int64_t n_win = ((int64_t)col_hi - col_lo) / win_cols + 1;
@@ -399,7 +399,8 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                                                              const float *__restrict__ e_val, const int32_t *__restrict__ dst,
                                                              int n_rowpass, int n_win, int n_slices, const float *__restrict__ E,
                                                              int64_t ldE, float *__restrict__ out, int64_t ldo,
-                                                             float *__restrict__ partial, int dp, unsigned *bar, int max_spin, int lead)
+                                                             float *__restrict__ partial, int dp, unsigned *bar, int max_spin, int lead,
+                                                             int sync_k)
 {
     __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
         const int64_t task = ((int64_t)rp * gridDim.x + blockIdx.x) * NW + wave;
         const int64_t *tp = tptr + task * n_win;
         const int64_t beg = tp[0], end = tp[n_win];
-        for (int slice = 0; slice < n_slices; ++slice, step0 += n_win) {
+        for (int slice = 0; slice < n_slices; ++slice, step0 += (n_win + sync_k - 1) / sync_k) {   // sweep step = sync_k windows
             const char *Eb = reinterpret_cast<const char *>(E + slice * kSW);   // uniform base + 32-bit lane offsets
             for (int i = lane; i < (RW + 1) * kSW; i += 64) wacc[i] = 0.f;
             int b = 0;
@@ -440,13 +441,13 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
             // windows left behind by a wave whose next slot is `pos`; then the permission to enter the new one
             auto cross = [&](int64_t pos, bool crossed) {
                 while (b < n_win - 1 && pos >= wend) {
-                    arrive(step0 + b);
+                    if ((b + 1) % sync_k == 0) arrive(step0 + b / sync_k);
                     ++b;
                     wend = wend_next;
                     wend_next = b + 2 <= n_win ? tp[b + 2] : end;
                     crossed = true;
                 }
-                const int s = step0 + b;         // the step being entered needs step s-1-lead finished by the whole XCD
+                const int s = step0 + b / sync_k;   // the step being entered needs step s-1-lead finished by the whole XCD
                 if (crossed && sync && max_spin > 0 && perm < s) {
                     perm = __hip_atomic_load(&perm_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     int spins = 0;
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
 #undef NGCF_ACC_HI
             }
             cross(INT64_MAX - 1, false);         // leave the remaining windows (b ends at n_win-1) ...
-            arrive(step0 + n_win - 1);           // ... and the last one
+            arrive(step0 + (n_win - 1) / sync_k);   // ... and the last step
             // write this wave's rows (its own LDS rows; a wave's LDS operations complete in order)
             for (int r0 = 0; r0 < RW; r0 += kEPR) {
                 const int r = r0 + g;
@@ -555,16 +556,22 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
 {
     const ngcf_csr::Swept &w = c->swept;
     const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);                       // polls before a wave stops waiting for good
-    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);        // windows a wave may run ahead (-1: no sync)
+    // The entry lists are laid out in 2 MiB column windows, the XCD-wide counters tick every third window, and a wave may
+    // be two such steps ahead: walking its list in ascending column order already keeps a wave near its neighbours (the
+    // working set at any moment is about one layout window), the counters only bound the drift.  Measured in one
+    // process on C3 (item rows / user rows): 4 MiB windows, one per step, lead 1: 2.07 / 2.08 ms; 2 MiB x 3, lead 2:
+    // 1.95 / 1.97 ms; 1 MiB x 6: 2.03 / 2.13 ms (more empty slots).
+    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 2), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
+    const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 3));       // layout windows per sweep step
     for (const auto &p : w.parts) {
         float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
         if (p.waves == 16)
             spmm_swept_kernel<kLdsRows / 16, 16><<<dim3(kSweptWGs), 16 * 64, 0, stream>>>(
-                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead);
+                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead, sync_k);
         else
             spmm_swept_kernel<kLdsRows / 8, 8><<<dim3(kSweptWGs), 8 * 64, 0, stream>>>(
-                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead);
+                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead, sync_k);
         LAUNCH_CHECK();
     }
     for (const auto &p : w.parts) {
