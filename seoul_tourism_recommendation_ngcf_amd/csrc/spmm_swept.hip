@@ -557,11 +557,12 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
     const ngcf_csr::Swept &w = c->swept;
     const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);                       // polls before a wave stops waiting for good
     // The entry lists are laid out in 2 MiB column windows, the XCD-wide counters tick every third window, and a wave may
-    // be two such steps ahead: walking its list in ascending column order already keeps a wave near its neighbours (the
-    // working set at any moment is about one layout window), the counters only bound the drift.  Measured in one
-    // process on C3 (item rows / user rows): 4 MiB windows, one per step, lead 1: 2.07 / 2.08 ms; 2 MiB x 3, lead 2:
-    // 1.95 / 1.97 ms; 1 MiB x 6: 2.03 / 2.13 ms (more empty slots).
-    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 2), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
+    // be one such step ahead: walking its list in ascending column order already keeps a wave near its neighbours (the
+    // working set at any moment is about one layout window), the counters only bound the drift.  bench.py on C3, same
+    // process: 4 MiB windows with a tick per window 15.1 ms/step (SpMM 4.16 ms); 2 MiB x 3: 14.3-14.4 (3.88-3.94) with
+    // lead 1, 14.6-14.7 with lead 2, 15.2 with lead 3, 16.1 with lead 0; 2 MiB x 2: 14.6; 2 MiB x 4 and 1.5 MiB x 4:
+    // 14.25; 1 MiB x 6: 14.5 (more empty slots).
+    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
     const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 3));       // layout windows per sweep step
     for (const auto &p : w.parts) {
         float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
