@@ -177,7 +177,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
         }
     }
     // 2) column windows and the slot layout of every (task, window) bucket
-    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", 2048);
+    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", 8192);
     if (win_kb < 16) win_kb = 16;
     const int32_t win_cols = (int32_t)std::max<int64_t>(64, win_kb * 1024 / (kSW * 4));
     const int64_t n_win = ((int64_t)col_hi - col_lo) / win_cols + 1;
@@ -193,11 +193,59 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
                 hist[(size_t)((col[(size_t)x] - col_lo) / win_cols) * RW + lr]++;
         }
     };
-    // rounds of a bucket: R = max(longest row, ceil(entries / 4)); row after row is laid down the rounds, so the
-    // entries of one row never share a round (they are read-modify-written in LDS without atomics)
+    // Layout of a (task, window) bucket, two ways (NGCF_SWEPT_ORDER):
+    //  "rows"  : R = max(longest row, ceil(entries / 4)) rounds; row after row is laid down the rounds (wrap-around rule)
+    //  "cols"  : entries sorted by column, rounds filled greedily in that order with entries of distinct rows (an entry
+    //            whose row is already in the round waits for the next one): the wave walks the window left to right
+    // Either way the entries of one row never share a round (they are read-modify-written in LDS without atomics).
+    const bool by_cols = !(getenv("NGCF_SWEPT_ORDER") && !strcmp(getenv("NGCF_SWEPT_ORDER"), "rows"));   // default: cols
+    struct Ent { int32_t col, lr; float v; };
+    // schedule of one bucket: slot list (index into `ents`, -1 = empty), a multiple of kEPR long
+    auto schedule_cols = [&](std::vector<Ent> &ents, std::vector<int32_t> &slots, std::vector<char> &done) {
+        std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.col != y.col ? x.col < y.col : x.lr < y.lr; });
+        slots.clear();
+        done.assign(ents.size(), 0);
+        size_t first = 0, left = ents.size();
+        while (left > 0) {
+            uint64_t in_round[2] = {0, 0};
+            int taken = 0;
+            while (first < ents.size() && done[first]) ++first;
+            for (size_t i = first; i < ents.size() && taken < kEPR && i < first + 512; ++i) {
+                if (done[i]) continue;
+                const int lr = ents[i].lr;
+                if (in_round[lr >> 6] >> (lr & 63) & 1) continue;
+                in_round[lr >> 6] |= (uint64_t)1 << (lr & 63);
+                done[i] = 1;
+                slots.push_back((int32_t)i);
+                ++taken;
+                --left;
+            }
+            for (; taken < kEPR; ++taken) slots.push_back(-1);
+        }
+    };
+    auto gather_bucket = [&](int64_t t, std::vector<std::vector<Ent>> &per_win) {
+        for (auto &v : per_win) v.clear();
+        for (int lr = 0; lr < RW; ++lr) {
+            const int64_t pi = task_piece[(size_t)(t * RW + lr)];
+            if (pi < 0) continue;
+            const Piece &pc = pieces[(size_t)pi];
+            for (int64_t x = pc.begin + pc.off; x < pc.end; x += pc.step)
+                per_win[(size_t)((col[(size_t)x] - col_lo) / win_cols)].push_back({col[(size_t)x], lr, val[(size_t)x]});
+        }
+    };
     parallel_for(n_tasks, [&](int64_t lo, int64_t hi) {
-        std::vector<int32_t> hist((size_t)n_win * RW);
+        std::vector<int32_t> hist((size_t)n_win * RW), slots;
+        std::vector<std::vector<Ent>> per_win(by_cols ? (size_t)n_win : 0);
+        std::vector<char> done;
         for (int64_t t = lo; t < hi; ++t) {
+            if (by_cols) {
+                gather_bucket(t, per_win);
+                for (int64_t w = 0; w < n_win; ++w) {
+                    schedule_cols(per_win[(size_t)w], slots, done);
+                    tptr[(size_t)(t * n_win + w) + 1] = (int64_t)slots.size();
+                }
+                continue;
+            }
             bucket_hist(t, hist);
             for (int64_t w = 0; w < n_win; ++w) {
                 int64_t total = 0, longest = 0;
@@ -215,9 +263,31 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     std::vector<int32_t> e_pack((size_t)std::max<int64_t>(n_slots, 1), -1);
     std::vector<float> e_val((size_t)std::max<int64_t>(n_slots, 1), 0.f);
     parallel_for(n_tasks, [&](int64_t lo, int64_t hi) {
-        std::vector<int32_t> hist((size_t)n_win * RW);
+        std::vector<int32_t> hist((size_t)n_win * RW), slots;
         std::vector<int64_t> rounds((size_t)n_win);
+        std::vector<std::vector<Ent>> per_win(by_cols ? (size_t)n_win : 0);
+        std::vector<char> done;
         for (int64_t t = lo; t < hi; ++t) {
+            if (by_cols) {
+                gather_bucket(t, per_win);
+                for (int64_t w = 0; w < n_win; ++w) {
+                    std::vector<Ent> &ents = per_win[(size_t)w];
+                    schedule_cols(ents, slots, done);
+                    const int64_t b0 = tptr[(size_t)(t * n_win + w)];
+                    int32_t near_col = ents.empty() ? 0 : ents[0].col;
+                    for (size_t i = 0; i < slots.size(); ++i) {
+                        if (slots[i] >= 0) {
+                            const Ent &e = ents[(size_t)slots[i]];
+                            near_col = e.col;
+                            e_pack[(size_t)b0 + i] = (int32_t)((uint32_t)e.lr << kRowBits) | e.col;
+                            e_val[(size_t)b0 + i] = e.v;
+                        } else {
+                            e_pack[(size_t)b0 + i] = (int32_t)((uint32_t)RW << kRowBits) | near_col;   // spare row, a row just gathered
+                        }
+                    }
+                }
+                continue;
+            }
             bucket_hist(t, hist);
             for (int64_t w = 0; w < n_win; ++w) {                   // hist -> first list position of every row in its bucket
                 rounds[(size_t)w] = (tptr[(size_t)(t * n_win + w) + 1] - tptr[(size_t)(t * n_win + w)]) / kEPR;
@@ -556,14 +626,14 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
 {
     const ngcf_csr::Swept &w = c->swept;
     const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);                       // polls before a wave stops waiting for good
-    // The entry lists are laid out in 2 MiB column windows, the XCD-wide counters tick every third window, and a wave may
-    // be one such step ahead: walking its list in ascending column order already keeps a wave near its neighbours (the
-    // working set at any moment is about one layout window), the counters only bound the drift.  bench.py on C3, same
-    // process: 4 MiB windows with a tick per window 15.1 ms/step (SpMM 4.16 ms); 2 MiB x 3: 14.3-14.4 (3.88-3.94) with
-    // lead 1, 14.6-14.7 with lead 2, 15.2 with lead 3, 16.1 with lead 0; 2 MiB x 2: 14.6; 2 MiB x 4 and 1.5 MiB x 4:
-    // 14.25; 1 MiB x 6: 14.5 (more empty slots).
+    // Inside a window a wave's entries are in ascending column order (plan, "cols" layout), so waves that enter a window
+    // together walk the table left to right together and the live set is a few hundred KiB; the XCD-wide counters tick
+    // once per 8 MiB window and a wave may be one window ahead - they only bound the drift.  bench.py on C3, same process:
+    // row-wise layout inside 4 MiB windows 15.1 ms/step (SpMM 4.16 ms), inside 2 MiB windows with a tick every third
+    // 14.3-14.4 (3.9); column order inside 8 MiB windows 13.65-13.7 (3.68-3.71), 6 MiB 13.8, 12 MiB 13.9, 16 MiB 14.3,
+    // 4 MiB 14.4; lead 0: 14.9, lead 2: 14.5.
     const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
-    const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 3));       // layout windows per sweep step
+    const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 1));       // windows per sweep step (lab knob)
     for (const auto &p : w.parts) {
         float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));

@@ -15,9 +15,9 @@ nu = int(torch.searchsorted(rows, torch.tensor([U], device=dev)))
 parts = {"user rows": (rows[:nu], cols[:nu], vals[:nu], U), "item rows": (rows[nu:] - U, cols[nu:], vals[nu:], I)}
 E = torch.randn((N, d), device=dev)
 ws = eng.Workspace()
-# windows as "KiB" or "KiB:K" (K layout windows per synchronised sweep step, NGCF_SWEPT_SYNC_EVERY)
+# windows as "KiB", "KiB:K" or "KiB:K:order" (K windows per synchronised sweep step; order = cols | rows inside a window)
 _w = [x.split(":") for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "2048,3072,4096,6144".split(","))]
-windows = [(int(x[0]), x[1] if len(x) > 1 else "1") for x in _w]
+windows = [(int(x[0]), x[1] if len(x) > 1 else "1", x[2] if len(x) > 2 else "cols") for x in _w]
 leads = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2".split(","))]
 
 
@@ -42,10 +42,11 @@ for name, (r, c, v, nr) in parts.items():
         ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
         print(f"{name}: {label:18s} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s", flush=True)
     ref = out.clone()
-    for (kb, every), waves, cut in [(k_, w_, c_) for k_ in windows for w_ in (os.environ.get("LAB_WAVES", "0").split(","))
+    for (kb, every, order), waves, cut in [(k_, w_, c_) for k_ in windows for w_ in (os.environ.get("LAB_WAVES", "0").split(","))
                                     for c_ in os.environ.get("LAB_CUT", "4").split(",")]:
         os.environ["NGCF_SWEPT_WINDOW_KB"] = str(kb)
         os.environ["NGCF_SWEPT_SYNC_EVERY"] = every
+        os.environ["NGCF_SWEPT_ORDER"] = order
         os.environ["NGCF_SWEPT_WAVES"] = waves
         os.environ["NGCF_SWEPT_CUT"] = cut
         csr.set_mode(1)
@@ -56,5 +57,5 @@ for name, (r, c, v, nr) in parts.items():
             os.environ["NGCF_SWEPT_LEAD"] = str(lead)
             ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
             err = float((out - ref).abs().max())
-            print(f"{name}: swept window {kb:5d} KiB x{every} waves {waves:>2s} cut T/{cut} lead {lead:2d} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
+            print(f"{name}: swept window {kb:5d} KiB x{every} {order} waves {waves:>2s} cut T/{cut} lead {lead:2d} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
                   f"(plan {tb:.1f} s, max diff {err:.1e})", flush=True)
