@@ -194,10 +194,12 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
     np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize("d", [64, 128, 256])
-def test_spmm_sliced_and_swept_kernels_large_matrix(d, dev):
+@pytest.mark.parametrize("d,order", [(64, "cols"), (128, "cols"), (256, "cols"), (128, "rows")])
+def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, monkeypatch):
     """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the L2-swept
-    kernel (forced) and the plain row-wise kernel must give the same product."""
+    kernel (forced; both layouts of a wave's entry list inside a window) and the plain row-wise kernel must give the
+    same product."""
+    monkeypatch.setenv("NGCF_SWEPT_ORDER", order)
     pkg = _pkg()
     eng = pkg.engine
     coo = pkg.graphs.synthetic_bipartite(150000, 12000, 2600000, seed=33, device=dev)
