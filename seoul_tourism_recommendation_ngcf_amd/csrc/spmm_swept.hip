@@ -7,20 +7,21 @@
 // XCD's L2 by the other output rows that need it.
 //
 // How: a persistent grid of 256 workgroups (one per CU).  Every wave owns up to RW output rows ("wave task") whose
-// accumulators - one 64-float slice each - stay in LDS for a whole sweep, so the chip's LDS holds 100 K row slices
+// accumulators - one 64-float slice each - stay in LDS for a whole sweep, so the chip's LDS holds 147 K row slices
 // at once; d is walked slice by slice, the rows in "row passes" when they do not fit at once.  The host plan deals
 // rows (long rows in strided pieces) to the wave tasks so that all tasks carry the same number of entries, and
-// lays each task's entries out window by window.  A round = one wave instruction = four entries (16 lanes x 16 B
-// each).  The contribution of an entry is added to its LDS row with a plain read-modify-write (LDS float atomics
-// were measured 15x slower), so inside a window the plan orders the entries such that the four entries of a round
-// belong to four different rows (wrap-around rule: row after row is laid down the rounds, R = max(longest row,
-// ceil(entries / 4)) rounds per window; < 2 % empty slots on C3).  A wave touches nothing but its own LDS rows
-// and adds in list order: the result is deterministic.
+// lays each task's entries out window by window (8 MiB of table slice), inside a window in ascending column order:
+// waves that enter a window together walk the table left to right together.  A round = one wave instruction = four
+// entries (16 lanes x 16 B each).  The contribution of an entry is added to its LDS row with a plain
+// read-modify-write (LDS float atomics were measured 15x slower), so the four entries of a round must belong to four
+// different rows: the rounds are filled greedily in column order, an entry whose row is already in the round waits
+// for the next one; slots that stay empty (~1 % on C3) point at a spare LDS row.  A wave touches nothing but its own
+// LDS rows and adds in list order: the result is deterministic.
 // The sweep is kept together per XCD (HW_REG_XCC_ID) by counters: a wave may enter window s once every workgroup
 // of its XCD has left window s-1-lead behind.  The spin is bounded and only serves speed - a grid that is not
 // resident together loses the L2 re-use, it never hangs and never changes the result.
 // Rows cut into pieces leave partial sums in the workspace; spmm_fixup_kernel adds them in piece order.
-// Measured on C3 (1x MI355X, d=128): item rows 1.98 ms vs 3.5 ms row-wise, user rows 2.06 vs 2.46 ms d-sliced.
+// Measured on C3 (1x MI355X, d=128): item rows 1.83-1.93 ms vs 3.5 ms row-wise, user rows 1.84-1.94 vs 2.46 ms d-sliced.
 #include "spmm_device.h"
 
 namespace {
