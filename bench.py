@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth of the 8 XCDs (same guide, "L2 (per XCD)")
 
 WORKLOADS = {
     # name: (n_user, n_item, interactions, d0, layers, seed)
@@ -48,7 +49,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--exchange", default="bipartite", choices=["bipartite", "allgather"])
+    ap.add_argument("--exchange", default="allgather", choices=["bipartite", "allgather"],
+                    help="N > 1: the scheme `value` is measured on (BASELINE config 4 = allgather); the other one is "
+                         "timed as a labelled secondary field of the same line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other exchange "
+                    "scheme at N > 1; the reference-legal 130-wide first layer through model.forward() at N = 1)")
     ap.add_argument("--seg-len", type=int, default=0, help="override the row-segment length (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-items", action="store_true", help="secondary line: no popularity skew")
@@ -83,25 +88,53 @@ def parity_spot_check(ref, model, coo, seed):
             "rtol": 2e-3, "ok": ok, "against": "oracle/ngcf_oracle.py propagate_torch (CPU restatement of NGCF.py:120-147)"}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(coo, model, n_threads, seed=0):
     """The reference's PyTorch CPU path (oracle/ngcf_oracle.py, bit-exact restatement) on a bounded sample:
-    ONE propagation layer (layer 1 of 3) of the same graph and weights, on this node's host cores."""
+    ONE propagation layer (layer 1 of 3) of the same graph and weights, on this node's host cores.  Protocol of SURVEY
+    8d: 1 warm-up + 3 timed repetitions, median, once with all of this process's host threads and once with 1."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ngcf_oracle as orc
     N = coo["n_user"] + coo["n_item"]
     idx = torch.stack([coo["rows"], coo["cols"]]).cpu()
     L = torch.sparse_coo_tensor(idx, coo["vals"].cpu(), (N, N))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    def one_layer():
+        with torch.no_grad():
+            return orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], [sd["w1_list.0.weight"]],
+                                       [sd["w1_list.0.bias"]], [sd["w2_list.0.weight"]], [sd["w2_list.0.bias"]])
+
+    def median_of_3(threads):
+        torch.set_num_threads(threads)
+        ref, times = one_layer(), []                          # warm-up (its result is the parity reference)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            one_layer()
+            times.append(time.perf_counter() - t0)
+        return ref, sorted(times)[1], times
+
+    ref, dt, times = median_of_3(n_threads)
+    _, dt1, times1 = median_of_3(1)
     torch.set_num_threads(n_threads)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ref = orc.propagate_torch(L, sd["user_embedding.weight"], sd["item_embedding.weight"], [sd["w1_list.0.weight"]],
-                                  [sd["w1_list.0.bias"]], [sd["w2_list.0.weight"]], [sd["w2_list.0.bias"]])
-    dt = time.perf_counter() - t0
-    return {"parity": parity_spot_check(ref, model, coo, seed), "value": coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
+    return {"parity": parity_spot_check(ref, model, coo, seed), "value": coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads,
+            "kind": "port", "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
             "sample": f"1 of 3 layers (SpMM + 3 Linear + LeakyReLU + normalize + cat) of the same graph, "
-                      f"nnz(L)={coo['nnz']}, d=128, torch {torch.__version__} CPU, {dt:.1f} s, single run",
-            "seconds": dt}
+                      f"nnz(L)={coo['nnz']}, d={sd['user_embedding.weight'].shape[1]}, torch {torch.__version__} CPU; "
+                      f"1 warm-up + 3 timed runs, median {dt:.1f} s at {n_threads} threads "
+                      f"(the sparse mm is single-threaded in torch CPU)",
+            "seconds": dt, "runs_seconds": [round(t, 2) for t in times],
+            "one_thread": {"value": coo["nnz"] / dt1, "unit": "edges/s", "cores": 1, "seconds": dt1,
+                           "runs_seconds": [round(t, 2) for t in times1]}}
 
 
 def cpu_baseline_full(coo, model, n_threads, seed=0):
@@ -125,6 +158,10 @@ def cpu_baseline_full(coo, model, n_threads, seed=0):
     return {"parity": parity_spot_check(ref, model, coo, seed), "value": n_layer * coo["nnz"] / dt, "unit": "edges/s", "cores": n_threads, "kind": "port",
             "sample": f"whole {n_layer}-layer propagation, median of 5 after 1 warm-up, torch {torch.__version__} CPU, {dt * 1e3:.1f} ms",
             "seconds": dt}
+
+
+def edges_per_step_of(n_layer, nnz):
+    return n_layer * nnz
 
 
 def main():
@@ -160,9 +197,15 @@ def main():
         if world != 1:
             raise SystemExit("the Seoul-shaped workloads are single-GPU configurations")
         coo = pkg.graphs.seoul_standin(dev, seed=seed, n_user=n_user, n_item=n_item)[0]
-    else:
+    elif world == 1:
         coo = pkg.graphs.synthetic_bipartite(n_user, n_item, n_inter, seed=seed, device=dev,
                                              item_skew=not args.uniform_items)
+    else:
+        # every rank draws the same interaction triplets and keeps only its own slabs (dist.from_interactions): the doubled
+        # [N, N] COO is never formed on any rank
+        inter = pkg.graphs.synthetic_interactions(n_user, n_item, n_inter, seed=seed, device=dev,
+                                                  item_skew=not args.uniform_items)
+        coo = {"nnz": int(2 * inter[0].numel()), "interactions": int(inter[0].numel()), "n_user": n_user, "n_item": n_item}
     nnz, N = coo["nnz"], n_user + n_item
     num_dict = {"user": n_user, "item": n_item, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
     torch.manual_seed(seed)                                   # same parameters on every rank
@@ -208,16 +251,9 @@ def main():
             n = pkg.engine.gather_rows(model.all_items_emb, neg, status)
             return crit(u, p, n)
     else:
-        sh = ngcf_dist.ShardedPropagation(model, coo["rows"], coo["cols"], coo["vals"], mode=args.exchange)
+        sh = ngcf_dist.ShardedPropagation.from_interactions(model, *inter, mode=args.exchange, device=dev)
         local_nnz = sh.local_nnz
-        if args.exchange == "bipartite":
-            spmm_shapes = [(sh.csr_it.nnz, sh.csr_it.n_rows, sh.csr_it.n_cols), (sh.csr_u.nnz, sh.csr_u.n_rows, sh.csr_u.n_cols)]
-        else:
-            spmm_shapes = [(sh.csr_i.nnz, sh.csr_i.n_rows, sh.csr_i.n_cols), (sh.csr_u.nnz, sh.csr_u.n_rows, sh.csr_u.n_cols)]
-        if args.seg_len:
-            for c in (sh.csr_u, getattr(sh, "csr_it", None), getattr(sh, "csr_i", None)):
-                if c is not None:
-                    c.plan(args.seg_len)
+        spmm_shapes = sh.spmm_shapes()
 
         def step():
             sh.propagate()
@@ -229,25 +265,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
-    for _ in range(args.warmup):
-        loss = step()
-    barrier()
-    lib.ngcf_prof_enable(1)                                   # hipEvent pair around every SpMM launch
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
     import ctypes as C
-    n_launch, spmm_ms = C.c_int64(), C.c_double()
-    _lib.check(lib.ngcf_prof_collect(C.byref(n_launch), C.byref(spmm_ms)))
-    lib.ngcf_prof_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(loss).item(), "non-finite loss"
+
+    def timed(step_fn, prof):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(args.warmup):
+            last = step_fn()
+        barrier()
+        if prof:
+            lib.ngcf_prof_enable(1)                           # hipEvent pair around every SpMM launch
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step_fn()
+        barrier()
+        el = time.perf_counter() - t0
+        n_l, ms = C.c_int64(), C.c_double()
+        if prof:
+            _lib.check(lib.ngcf_prof_collect(C.byref(n_l), C.byref(ms)))
+            lib.ngcf_prof_enable(0)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        assert torch.isfinite(last).item(), "non-finite loss"
+        return el, last, n_l, ms
+
+    torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
+    dt, loss, n_launch, spmm_ms = timed(step, True)
 
     n_layer = len(layers)
     edges_per_step = n_layer * nnz                            # whole job, all ranks
@@ -256,14 +300,53 @@ def main():
     per_launch = sum(spmm_model_a_bytes(z, r_, c_, d0) for z, r_, c_ in spmm_shapes) / len(spmm_shapes)
     mean_ms = spmm_ms.value / max(n_launch.value, 1)
     achieved = per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")    # PMC-measured HBM bytes per launch (rocprofv3 --pmc)
     if os.path.exists(tpath) and world == 1:
         rec = json.load(open(tpath)).get(args.workload + ("_uniform" if args.uniform_items else ""))
         if rec and rec.get("seg_len", 0) == (args.seg_len or rec.get("seg_len", 0)):
             traffic = rec["hbm_bytes_per_spmm_launch"]
+            traffic_source = ("profiles/traffic.json - NOT measured in this run: separate rocprofv3 --pmc passes of this "
+                              "command (tools/pmc.sh), " + rec.get("version", "") + ", " + rec.get("collected", ""))
+    gather_bytes = (local_nnz / max(len(spmm_shapes), 1) if world > 1 else nnz) * d0 * 4
 
-    swept = [c_.swept_rows for c_ in ([csr] if world == 1 else [sh.csr_u, getattr(sh, "csr_it", None) or sh.csr_i])]
+    secondary = {}
+    if world > 1 and not args.no_secondary:
+        other = "bipartite" if args.exchange == "allgather" else "allgather"
+        sh2 = ngcf_dist.ShardedPropagation.from_interactions(model, *inter, mode=other, device=dev)
+
+        def step2():
+            sh2.propagate()
+            u, p, n = sh2.gather(u_id, pos, neg)
+            return crit(u, p, n)
+        dt2, loss2, _, _ = timed(step2, False)
+        secondary[f"exchange_{other}"] = {"value": edges_per_step_of(len(layers), nnz) * args.steps / dt2, "unit": "edges/s",
+                                          "ms_per_step": dt2 / args.steps * 1e3, "loss": float(loss2),
+                                          "note": ngcf_dist.SCHEME_NOTES[other]}
+        del sh2
+    if world == 1 and not seoul and not args.no_secondary and d0 % 5 != 0:
+        # the widths the reference can actually run (embed_size must be a multiple of 5, NGCF.py:39-43,114): same graph,
+        # embed_size = 5*ceil(d0/5) -> [d0]*n, through the whole model.forward() including the feature injection
+        d5 = (d0 + 4) // 5 * 5
+        torch.manual_seed(seed)
+        m5 = pkg.NGCF(d5, list(layers), None, None, 1.0, [lap], num_dict, args.batch, dev).to(dev).eval()
+        m5.check_indices = False
+        feats = {k: torch.randint(0, c, (args.batch,), generator=g).to(dev)
+                 for k, c in (("age", 76), ("sex", 2), ("month", 13), ("day", 32), ("dow", 7))}
+        year = torch.full((args.batch,), 18, device=dev)
+
+        def step5():
+            u, p, n = m5(year=year, u_id=u_id, pos_item=pos, neg_item=neg, node_flag=False, **feats)
+            return crit(u, p, n)
+        dt5, loss5, _, _ = timed(step5, False)
+        secondary[f"reference_legal_{d5}_to_{d0}"] = {
+            "value": len(layers) * nnz * args.steps / dt5, "unit": "edges/s", "ms_per_step": dt5 / args.steps * 1e3,
+            "ratio_to_headline": dt5 / dt, "loss": float(loss5),
+            "note": f"embed_size={d5}, layer_size={list(layers)}: whole NGCF.forward (feature injection, propagation, "
+                    f"gathers) + BPR; the headline runs d0={d0}, which the reference itself cannot (NGCF.py:39-43,114)"}
+        del m5
+
+    swept = [csr.swept_rows] if world == 1 else sh.swept_rows()
     kernel_name = ("spmm_swept_kernel (one L.E product: a launch per row group + fix-up)" if all(swept) else
                    "spmm_kernel + spmm_sliced_kernel (one L.E product)" if not any(swept) else
                    "spmm_swept_kernel / spmm_kernel (one L.E product, mean over the rank's two products)")
@@ -282,10 +365,19 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
-                     "mean_launch_ms": mean_ms, "swept_rows": swept,
-                     "gather_bytes_per_launch": local_nnz / max(len(spmm_shapes), 1) * d0 * 4 if world > 1 else nnz * d0 * 4},
+                     "traffic_source": traffic_source,
+                     "mean_launch_ms": mean_ms, "swept_rows": swept},
+        # what actually bounds the SpMM on a graph without locality: every stored entry gathers one row slice of E through
+        # the vector L1 from L2 (4*d bytes per entry, 26x the algorithmic bytes at C3); see DESIGN.md 4.1
+        "roofline_l2": {"bound": "l2-gather", "kernel": kernel_name, "achieved": gather_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0,
+                        "peak": L2_PEAK_GBS, "unit": "GB/s",
+                        "frac": (gather_bytes / (mean_ms * 1e-3) / 1e9 / L2_PEAK_GBS) if mean_ms > 0 else 0.0,
+                        "gather_bytes_per_launch": gather_bytes,
+                        "note": "explanatory, not the headline: roofline.frac stays SURVEY 8d model A"},
         "loss": float(loss),
     }
+    if secondary:
+        out["secondary"] = secondary
     if seoul:
         out["roofline"]["note"] = "working set is cache-resident at this size: the HBM fraction is not meaningful (SURVEY 8d)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and seoul:

@@ -130,11 +130,16 @@ int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE
  * layer) feeds the next layer; `norm` is written straight into its column block of all_E
  * (pointer already offset by the block's first column, leading dimension ldn = ld of all_E),
  * which removes the reference's `torch.cat` (NGCF.py:147).  drop_p == 0 -> no dropout (eval).
+ * Message dropout (NGCF.py:142), two forms: `drop_mask` != NULL ([n_rows, d_out], leading dimension ld_mask) is the
+ * noise tensor nn.Dropout multiplies by (0 or 1/(1-p)), drawn by the caller - the mirror draws it from torch's CPU
+ * generator exactly where the reference does, so the zero pattern is bit-identical ("reference" mode); drop_mask == NULL
+ * and drop_p > 0: keep mask = counter-based hash of (drop_seed, row, column) evaluated in the epilogue ("device" mode).
  */
 int ngcf_layer_fused_f32(const ngcf_csr_t *csr, const float *E_gather, int64_t ldEg,
                          const float *E_self, int64_t ldEs, int d_in,
                          const float *W1, const float *b1, const float *W2, const float *b2, int d_out,
                          float leaky_slope, float drop_p, uint64_t drop_seed,
+                         const float *drop_mask, int64_t ld_mask,
                          float *carry, int64_t ldc, float *norm, int64_t ldn,
                          void *workspace, int64_t workspace_bytes, void *stream);
 
@@ -145,6 +150,7 @@ int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *E_self, int
                          int64_t n_rows, int d_in,
                          const float *W1, const float *b1, const float *W2, const float *b2, int d_out,
                          float leaky_slope, float drop_p, uint64_t drop_seed,
+                         const float *drop_mask, int64_t ld_mask,
                          float *carry, int64_t ldc, float *norm, int64_t ldn,
                          void *workspace, int64_t workspace_bytes, void *stream);
 
@@ -200,8 +206,8 @@ int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, i
 /* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block),
  * dC (gradient of the carry from the next layer, may be NULL) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
-                           int64_t n_rows, int d, float leaky_slope, float drop_p, uint64_t drop_seed, float *dM,
-                           int64_t ldm, void *stream);
+                           int64_t n_rows, int d, float leaky_slope, float drop_p, uint64_t drop_seed,
+                           const float *drop_mask, int64_t ld_mask, float *dM, int64_t ldm, void *stream);
 /* SP[n_rows, 2d] = [LE + E | LE * E], the forward GEMM operand (NGCF.py:131-136), needed for dW1/dW2. */
 int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ldE, int64_t n_rows, int d, float *SP,
                        void *stream);
@@ -233,6 +239,19 @@ int ngcf_topk_rows_f32(const float *scores, int64_t ld, int64_t n_rows, int64_t 
  */
 int ngcf_shard_plan(const int64_t *rowptr_host, int64_t row_begin, int64_t row_end, int world,
                     int64_t *bounds_host);
+
+/*
+ * The exchange step between two layers of the row-partitioned engine (the reference is
+ * single-device, NGCF.py has no counterpart): recv[q*rows_per_rank + k, :] = rank q's send[k, :] for every rank q of
+ * the communicator - one ncclAllGather (RCCL over xGMI) of rows_per_rank*d floats per rank, asynchronous on `stream`.
+ * `nccl_comm` is an ncclComm_t passed as void* (the Python mirror hands over its process group's communicator);
+ * send: [rows_per_rank, d] contiguous, recv: [n_ranks*rows_per_rank, d] contiguous, both device pointers.  With the
+ * padded rank-major numbering of dist.ShardLayout the received block IS the replica the next layer gathers from.
+ * The library binds to the librccl already loaded in the process (it does not link one).
+ */
+int ngcf_allgather_rows(void *nccl_comm, const float *send, float *recv, int64_t rows_per_rank, int d, void *stream);
+/* number of ranks of the communicator (host call) */
+int ngcf_comm_size(void *nccl_comm, int *n_ranks);
 
 #ifdef __cplusplus
 }

@@ -63,9 +63,15 @@ class NGCF(nn.Module):
                     self.month_emb, self.dow_emb, self.day_emb):    # NGCF.py:58-68
             nn.init.kaiming_uniform_(emb.weight)
 
+        # W1_k then W2_k per layer, as set_layers does (NGCF.py:73-78): the same torch.manual_seed then gives the same
+        # initial Linear weights as the reference class (tests/test_reference_checkpoints.py)
         dims = [self.emb_size] + list(self.weight_size)
-        self.w1_list = nn.Sequential(*[nn.Linear(dims[k], dims[k + 1], bias=True) for k in range(self.n_layer)])
-        self.w2_list = nn.Sequential(*[nn.Linear(dims[k], dims[k + 1], bias=True) for k in range(self.n_layer)])
+        w1, w2 = [], []
+        for k in range(self.n_layer):
+            w1.append(nn.Linear(dims[k], dims[k + 1], bias=True))
+            w2.append(nn.Linear(dims[k], dims[k + 1], bias=True))
+        self.w1_list = nn.Sequential(*w1)
+        self.w2_list = nn.Sequential(*w2)
         self.node_dropout_list = nn.Sequential(
             *[nn.Dropout(p=self.node_dropout) for _ in range(self.n_layer if self.node_dropout is not None else 0)])
         self.mess_dropout_list = nn.Sequential(
@@ -78,7 +84,11 @@ class NGCF(nn.Module):
         self._scratch: Optional[torch.Tensor] = None
         self._status: Optional[torch.Tensor] = None
         self.check_indices = True        # raise IndexError on out-of-range ids (one host sync per forward)
+        # where the random masks come from: "reference" = torch's default CPU generator, drawn exactly where the reference
+        # draws (bit-identical masks for the same torch.manual_seed, one host round trip per layer); "device" = counter
+        # hash evaluated inside the kernels (same distribution and semantics, another stream, no host work)
         self.node_dropout_mode = "reference"
+        self.mess_dropout_mode = "reference"
         self.all_users_emb = None
         self.all_items_emb = None
         self._all_E = None
@@ -160,27 +170,47 @@ class NGCF(nn.Module):
         return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],
                 [l.weight for l in self.w2_list], [l.bias for l in self.w2_list])
 
-    def _dropped_csr_list(self, year_idx: int):
-        """Cumulative, unscaled node dropout of NGCF.py:93-100,124-126 ("reference" mode).
-
-        The keep mask is drawn exactly as the reference does - `nn.Dropout(p)` on float64 ones from the
-        CPU default generator, once per layer on the already thinned matrix - so the kept edge sets are
-        bit-identical for the same `torch.manual_seed`.  Each layer gets its own (smaller) CSR.
+    def _reference_draws(self, year_idx: int, node_ref: bool, drop, mess_ref: bool):
+        """Everything the reference draws from torch's default CPU generator during one forward, in its order
+        (NGCF.py:123-142): per layer first the node-dropout keep mask (`nn.Dropout(p)` on float64 ones, on the
+        matrix already thinned by the earlier layers: cumulative, unscaled, NGCF.py:93-100), then the message-dropout
+        noise tensor (`nn.Dropout(p_k)` on the [N, d_k+1] activations, NGCF.py:142; no draw for p == 0, as in torch).
+        Same `torch.manual_seed` -> bit-identical kept edge sets and zero patterns as the reference on CPU.
+        Returns (per-layer thinned CSRs or None, their transposes' builder or None, per-layer noise tensors or None).
         """
         dev = self._dev()
-        L = self.lap_list[year_idx]
-        idx = L._indices().to(dev)
-        val = L._values().to(device=dev, dtype=torch.float32)
         N = self.n_user + self.n_item
-        out, kept = [], []
-        for _ in range(self.n_layer):
-            mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
-                                               p=self.node_dropout, training=True).type(torch.bool).to(dev)
-            idx, val = idx[:, mask], val[mask]
-            out.append(_eng.LaplacianCSR.from_coo(idx[0], idx[1], val, N, N))
-            kept.append((idx, val))
+        widths = [self.emb_size] + list(self.weight_size)
+        csrs, kept, masks = [], [], []
+        if node_ref:
+            L = self.lap_list[year_idx]
+            idx = L._indices().to(dev)
+            val = L._values().to(device=dev, dtype=torch.float32)
+        for k in range(self.n_layer):
+            if node_ref:
+                mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
+                                                   p=self.node_dropout, training=True).type(torch.bool).to(dev)
+                idx, val = idx[:, mask], val[mask]
+                csrs.append(_eng.LaplacianCSR.from_coo(idx[0], idx[1], val, N, N))
+                kept.append((idx, val))
+            if mess_ref and drop[k] > 0:
+                noise = torch.nn.functional.dropout(torch.ones((N, widths[k + 1]), dtype=torch.float32),
+                                                    p=drop[k], training=True)
+                masks.append(noise.to(dev, non_blocking=False))
+            else:
+                masks.append(None)
         # the thinned matrices are not symmetric: their transposes are built only if a backward needs them
-        return out, (lambda: [self._transposed_csr(i, v) for i, v in kept])
+        return (csrs if node_ref else None, (lambda: [self._transposed_csr(i, v) for i, v in kept]) if node_ref else None,
+                masks if mess_ref else None)
+
+    def _private_seeds(self, n: int):
+        """64-bit seeds for the device-mode hash streams, from a generator of the module's own: the default CPU stream is
+        consumed only where the reference consumes it.  Follows torch.manual_seed (re-seeded when the default seed changes)."""
+        src = torch.initial_seed()
+        if getattr(self, "_seed_gen", None) is None or self._seed_src != src:
+            self._seed_gen = torch.Generator(device="cpu").manual_seed(src ^ 0x5DEECE66D)
+            self._seed_src = src
+        return [int(x) for x in torch.randint(0, 2 ** 62, (n,), dtype=torch.int64, generator=self._seed_gen)]
 
     # ------------------------------------------------------------------------------------
     # propagation (NGCF.py:120-149)
@@ -188,28 +218,33 @@ class NGCF(nn.Module):
     def propagate(self, year_idx: int = 0, node_flag: bool = False) -> torch.Tensor:
         """all_E = [E0 | norm(E1) | ... | norm(En)]  for the current parameters; sets all_users_emb/all_items_emb."""
         self._dev()
+        if self.node_dropout_mode not in ("reference", "device"):
+            raise ValueError("node_dropout_mode must be 'reference' or 'device'")
+        if self.mess_dropout_mode not in ("reference", "device"):
+            raise ValueError("mess_dropout_mode must be 'reference' or 'device'")
+        drop = [0.0] * self.n_layer
+        if self.training and self.mess_dropout is not None:            # nn.Dropout follows train()/eval(), NGCF.py:142
+            drop = [float(p) for p in self.mess_dropout[:self.n_layer]]
+        node_ref = bool(node_flag) and self.node_dropout_mode == "reference"
+        mess_ref = any(p > 0 for p in drop) and self.mess_dropout_mode == "reference"
+        csrs, csrs_t_fn, masks = None, None, None
+        if node_ref or mess_ref:
+            csrs, csrs_t_fn, masks = self._reference_draws(year_idx, node_ref, drop, mess_ref)
         edge_drops = None
-        if node_flag and self.node_dropout_mode == "reference":
-            csrs, csrs_t_fn = self._dropped_csr_list(year_idx)
-        else:
+        if csrs is None:
             csrs = [self.laplacian_csr(year_idx)] * self.n_layer
             csrs_t_fn = lambda: [self.laplacian_csr_t(year_idx)] * self.n_layer   # noqa: E731
             if node_flag:
                 # "device" mode: same semantics (cumulative, unscaled), mask = counter-based hash of the entry number
-                # evaluated inside the SpMM kernel; one 64-bit seed per layer from torch's CPU generator
-                if self.node_dropout_mode != "device":
-                    raise ValueError("node_dropout_mode must be 'reference' or 'device'")
-                ns = [int(x) for x in torch.randint(0, 2 ** 62, (self.n_layer,), dtype=torch.int64)]
+                # evaluated inside the SpMM kernel; one 64-bit seed per layer
+                ns = self._private_seeds(self.n_layer)
                 edge_drops = [(ns[:k + 1], float(self.node_dropout)) for k in range(self.n_layer)]
-        drop = [0.0] * self.n_layer
-        if self.training and self.mess_dropout is not None:            # nn.Dropout follows train()/eval(), NGCF.py:142
-            drop = [float(p) for p in self.mess_dropout[:self.n_layer]]
         seeds = [0] * self.n_layer
-        if any(p > 0 for p in drop):
-            seeds = [int(s) for s in torch.randint(0, 2 ** 62, (self.n_layer,), dtype=torch.int64)]
+        if any(p > 0 for p in drop) and masks is None:                 # "device" mode: hash stream in the layer epilogue
+            seeds = self._private_seeds(self.n_layer)
         w1, b1, w2, b2 = self._layer_params()
         all_E = propagate_with_grad(self, csrs, csrs_t_fn, self.user_embedding.weight, self.item_embedding.weight,
-                                    w1, b1, w2, b2, drop, seeds, edge_drops)
+                                    w1, b1, w2, b2, drop, seeds, edge_drops, masks)
         self._all_E = all_E
         self.all_users_emb = all_E[:self.n_user, :]                    # NGCF.py:148-149
         self.all_items_emb = all_E[self.n_user:, :]

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import torch  # noqa: F401  (must be loaded before libngcf_hip.so, see module docstring)
 
@@ -44,9 +45,9 @@ PROTOTYPES = {
     "ngcf_spmm_csr_dropout_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, _vp,
                                             _vp, _i64, _vp]),
     "ngcf_layer_fused_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
-                                       _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+                                       _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_layer_dense_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
-                                       _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+                                       _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_copy_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_feature_inject_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_i64), C.c_int, _vp, _i64, C.c_double, _vp, _vp, _vp]),
@@ -55,7 +56,8 @@ PROTOTYPES = {
     "ngcf_bpr_fused_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp]),
     "ngcf_bpr_backward_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ngcf_scatter_add_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
-    "ngcf_layer_bwd_pre_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _f32, _f32, _u64, _vp, _i64, _vp]),
+    "ngcf_layer_bwd_pre_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _f32, _f32, _u64, _vp, _i64,
+                                         _vp, _i64, _vp]),
     "ngcf_sp_concat_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     "ngcf_layer_bwd_combine_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_bwd_weight_workspace_bytes": (_i64, []),
@@ -63,6 +65,8 @@ PROTOTYPES = {
     "ngcf_add_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_topk_rows_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp]),
     "ngcf_shard_plan": (C.c_int, [C.POINTER(_i64), _i64, _i64, C.c_int, C.POINTER(_i64)]),
+    "ngcf_allgather_rows": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
+    "ngcf_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -73,17 +77,26 @@ def lib_path() -> str:
 
 
 def load():
-    """Load libngcf_hip.so (building it first if the sources are newer).  Raises on failure."""
+    """Load libngcf_hip.so.  The library is built by `python __graft_entry__.py build` (before any GPU or profiler
+    start).  If it is missing or its sources changed since, it is rebuilt here under a file lock - unless NGCF_NO_BUILD=1
+    (set it under rocprofv3 and wherever a compiler must not be spawned): then a missing library raises and a stale one
+    is loaded with a loud warning.  A failed rebuild always raises; a stale library is never used silently."""
     global _lib
     if _lib is not None:
         return _lib
     if _build.needs_build():
-        try:
-            _build.build()
-        except Exception as exc:  # noqa: BLE001
+        if os.environ.get("NGCF_NO_BUILD") == "1":
             if not os.path.exists(_build.LIB):
+                raise RuntimeError(f"{_build.LIB} is not built and NGCF_NO_BUILD=1; run `python __graft_entry__.py build`. "
+                                   "This package has no CPU or PyTorch fallback.")
+            sys.stderr.write(f"[ngcf] WARNING: {_build.LIB} is OLDER than its sources (NGCF_NO_BUILD=1: not rebuilding); "
+                             "results come from the stale library. Run `python __graft_entry__.py build`.\n")
+        else:
+            try:
+                _build.build()
+            except Exception as exc:  # noqa: BLE001
                 raise RuntimeError(
-                    "libngcf_hip.so is not built and could not be built here: " + str(exc)
+                    "libngcf_hip.so is missing or older than its sources and could not be rebuilt here: " + str(exc)
                     + "\nThis package has no CPU or PyTorch fallback; run `python __graft_entry__.py build`.") from exc
     try:
         lib = C.CDLL(_build.LIB, mode=C.RTLD_GLOBAL)

@@ -36,7 +36,7 @@ def _first_layer_input(owner, user_w, item_w, all_E, U, d0):
 
 
 def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.Tensor, item_w: torch.Tensor,
-                      w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int], edge_drops=None):
+                      w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int], edge_drops=None, masks=None):
     """all_E [N, D] = [E0 | norm(E1) | ... | norm(En)] (NGCF.py:120-147), inference path.
 
     E0 is written once into its column block of all_E (this is both the `cat` of NGCF.py:120 and
@@ -64,13 +64,14 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
                 buf = torch.empty((N, d_out), dtype=torch.float32, device=dev)
                 owner._carry[k % 2] = buf
             carry = buf
+        mk = None if masks is None else masks[k]
         if edge_drops is None:
             _eng.layer_fused(csrs[k], prev, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(),
-                             carry, all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
+                             carry, all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k], mk)
         else:   # device-side node dropout: thinned SpMM, then the dense half
             LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=(edge_drops[k][0], edge_drops[k][1], None))
             _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
-                             all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
+                             all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k], mk)
         prev = carry
         off += d_out
     return all_E
@@ -79,7 +80,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
 # ------------------------------------------------------------------------------------------------
 # thin wrappers of the backward entry points
 # ------------------------------------------------------------------------------------------------
-def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed):
+def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None):
     lib = _lib.load()
     n_rows, d = Cc.shape
     dM = torch.empty((n_rows, d), dtype=torch.float32, device=Cc.device)
@@ -87,6 +88,7 @@ def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed):
         _lib.check(lib.ngcf_layer_bwd_pre_f32(_ptr(dN), _row_major_ld(dN, "dN"), _ptr(dC),
                                               0 if dC is None else _row_major_ld(dC, "dC"), _ptr(Cc),
                                               _row_major_ld(Cc, "C"), n_rows, d, leaky, float(drop_p), int(seed),
+                                              _ptr(mask), 0 if mask is None else _row_major_ld(mask, "drop_mask"),
                                               _ptr(dM), d, _stream()))
     return dM
 
@@ -150,7 +152,7 @@ class Propagate(torch.autograd.Function):
     """all_E = propagate(E0; W) with a hand-written backward (NGCF.py:120-147)."""
 
     @staticmethod
-    def forward(ctx, owner, csrs, csrs_t, drop, seeds, edge_drops, n_layer, user_w, item_w, *params):
+    def forward(ctx, owner, csrs, csrs_t, drop, seeds, edge_drops, masks, n_layer, user_w, item_w, *params):
         w1, b1 = params[:n_layer], params[n_layer:2 * n_layer]
         w2, b2 = params[2 * n_layer:3 * n_layer], params[3 * n_layer:]
         dev = user_w.device
@@ -169,14 +171,14 @@ class Propagate(torch.autograd.Function):
             LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=ed)        # saved for the backward
             carry = torch.empty((N, d_out), dtype=torch.float32, device=dev)
             _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
-                             all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k])
+                             all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k], None if masks is None else masks[k])
             ins.append(prev)
             les.append(LE)
             carries.append(carry)
             prev = carry
             off += d_out
         ctx.owner, ctx.csrs_t, ctx.drop, ctx.seeds, ctx.n_layer = owner, csrs_t, drop, seeds, n_layer
-        ctx.edge_drops = edge_drops
+        ctx.edge_drops, ctx.masks = edge_drops, masks
         ctx.widths, ctx.U = widths, U
         ctx.save_for_backward(all_E, *les, *carries, *[p.detach() for p in params])
         return all_E
@@ -198,7 +200,8 @@ class Propagate(torch.autograd.Function):
             d_in, d_out = widths[k], widths[k + 1]
             E_k = all_E[:, :widths[0]] if k == 0 else carries[k - 1]
             LE_k, C_k = les[k], carries[k]
-            dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k])
+            dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
+                          None if ctx.masks is None else ctx.masks[k])
             gW = _bwd_weight(dM, LE_k, E_k, ws)                                  # MFMA kernel, operand formed on the fly
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
             gb = dM.sum(0)
@@ -211,7 +214,7 @@ class Propagate(torch.autograd.Function):
             dC = dE
         dE0 = dC
         _add_rows(dE0, g_all[:, :widths[0]])                                     # the all_E block of E0 itself
-        return (None, None, None, None, None, None, None, dE0[:U], dE0[U:], *gw1, *gb1, *gw2, *gb2)
+        return (None, None, None, None, None, None, None, None, dE0[:U], dE0[U:], *gw1, *gb1, *gw2, *gb2)
 
 
 class GatherTriple(torch.autograd.Function):
@@ -266,11 +269,13 @@ class BPRLoss(torch.autograd.Function):
         return du, dp, dn, None, None, None
 
 
-def propagate_with_grad(owner, csrs, csrs_t_fn, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops=None) -> torch.Tensor:
+def propagate_with_grad(owner, csrs, csrs_t_fn, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops=None,
+                        masks=None) -> torch.Tensor:
     """Inference path unless a gradient can flow; then the autograd Function (needs the CSRs of L^T)."""
     params = list(w1) + list(b1) + list(w2) + list(b2)
     need = torch.is_grad_enabled() and any(t.requires_grad for t in [user_w, item_w] + params)
     if not need:
         with torch.no_grad():
-            return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops)
-    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), list(seeds), edge_drops, len(w1), user_w, item_w, *params)
+            return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops, masks)
+    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), list(seeds), edge_drops, masks, len(w1), user_w, item_w,
+                           *params)

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
                                                             const float *__restrict__ dC, int64_t ldc,
                                                             const float *__restrict__ C, int64_t ldC, int64_t n_rows,
                                                             int d, float leaky, float drop_p, uint64_t seed,
+                                                            const float *__restrict__ drop_mask, int64_t ldk,
                                                             float *__restrict__ dM, int64_t ldm)
 {
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
     for (int j = lane; j < d; j += 64) {
         float t = g[j] / den - c[j] * (ydot / den);
         if (dC) t += dC[r * ldc + j];
-        if (drop_p > 0.f) {
+        if (drop_mask) {
+            t *= drop_mask[r * ldk + j];                      // the host-drawn noise tensor of the forward (0 or 1/(1-p))
+        } else if (drop_p > 0.f) {
             const uint32_t h = mix32(seed ^ ((uint64_t)r * 0x9E3779B97F4A7C15ULL + (uint64_t)j));
             t = h < thr ? 0.f : t * keep_scale;
         }
@@ -126,14 +129,14 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
 }
 
 extern "C" int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
-                                      int64_t n_rows, int d, float leaky, float drop_p, uint64_t seed, float *dM, int64_t ldm,
-                                      void *stream_)
+                                      int64_t n_rows, int d, float leaky, float drop_p, uint64_t seed, const float *drop_mask,
+                                      int64_t ld_mask, float *dM, int64_t ldm, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows == 0) return NGCF_OK;
     if (!dN || !C || !dM || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_pre: bad argument");
     layer_bwd_pre_kernel<<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
-                                                                                 seed, dM, ldm);
+                                                                                 seed, drop_mask, ld_mask, dM, ldm);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

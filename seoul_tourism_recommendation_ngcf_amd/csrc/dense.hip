@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
                                                           int d_in, int d_out, const float *__restrict__ Wt,
                                                           const float *__restrict__ bias2, int n_chunks,
                                                           float leaky, float drop_p, uint64_t drop_seed,
+                                                          const float *__restrict__ drop_mask, int64_t ldm,
                                                           float *__restrict__ carry, int64_t ldc,
                                                           float *__restrict__ norm, int64_t ldn)
 {
@@ -190,7 +191,10 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
         for (int r = 0; r < 16; ++r) {
             float v = acc[t][r] + bz;
             v = v >= 0.f ? v : leaky * v;
-            if (drop_p > 0.f) {
+            if (drop_mask) {       // "reference" mode: the noise tensor nn.Dropout drew on the host (0 or 1/(1-p)), NGCF.py:142
+                const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
+            } else if (drop_p > 0.f) {
                 const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
                 v = h < drop_thr ? 0.f : v * keep_scale;
@@ -269,28 +273,29 @@ extern "C" int64_t ngcf_dense_workspace_bytes(int d_in, int d_out)
 template <int RW, int CW, int NT>
 static int launch_dense(bool al, int64_t n_rows, const float *LE, int64_t ldLE, const float *Es, int64_t ldE, int d_in,
                         int d_out, const float *Wt, const float *bias2, int n_chunks, float leaky, float drop_p,
-                        uint64_t seed, float *carry, int64_t ldc, float *norm, int64_t ldn, hipStream_t stream)
+                        uint64_t seed, const float *drop_mask, int64_t ldm, float *carry, int64_t ldc, float *norm, int64_t ldn,
+                        hipStream_t stream)
 {
     const int64_t blocks = (n_rows + 32 * RW - 1) / (32 * RW);
     if (blocks == 0) return NGCF_OK;
     if (al && d_in % NGCF_DC == 0)
         layer_dense_kernel<RW, CW, NT, true, true><<<dim3((unsigned)blocks), 256, 0, stream>>>(
-            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, drop_mask, ldm, carry, ldc, norm, ldn);
     else if (al)
         layer_dense_kernel<RW, CW, NT, true, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
-            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, drop_mask, ldm, carry, ldc, norm, ldn);
     else
         layer_dense_kernel<RW, CW, NT, false, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(
-            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, carry, ldc, norm, ldn);
+            LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, drop_mask, ldm, carry, ldc, norm, ldn);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
 
 extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *Es, int64_t ldEs, int64_t n_rows,
                                     int d_in, const float *W1, const float *b1, const float *W2, const float *b2,
-                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, float *carry,
-                                    int64_t ldc, float *norm, int64_t ldn, void *workspace, int64_t workspace_bytes,
-                                    void *stream_)
+                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, const float *drop_mask,
+                                    int64_t ld_mask, float *carry, int64_t ldc, float *norm, int64_t ldn, void *workspace,
+                                    int64_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!LE || !Es || !W1 || !b1 || !W2 || !b2 || !norm) return fail(NGCF_ERR_ARG, "layer_dense: null argument");
@@ -298,7 +303,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const int dop = dense_dop(d_out);
     if (dop < 0) return fail(NGCF_ERR_ARG, "layer_dense: d_out=%d > 512 is not supported", d_out);
     if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "layer_dense: drop_p=%f not in [0,1)", drop_p);
-    if (ldLE < d_in || ldEs < d_in || ldn < d_out || (carry && ldc < d_out))
+    if (ldLE < d_in || ldEs < d_in || ldn < d_out || (carry && ldc < d_out) || (drop_mask && ld_mask < d_out))
         return fail(NGCF_ERR_ARG, "layer_dense: leading dimension too small");
     const int64_t need = ngcf_dense_workspace_bytes(d_in, d_out);
     if (!workspace || workspace_bytes < need)
@@ -311,7 +316,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
 #define NGCF_DENSE(RW, CW, NT) \
     return launch_dense<RW, CW, NT>(al, n_rows, LE, ldLE, Es, ldEs, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, \
-                                    drop_seed, carry, ldc, norm, ldn, stream)
+                                    drop_seed, drop_mask, ld_mask, carry, ldc, norm, ldn, stream)
     switch (dop) {
     case 32: NGCF_DENSE(4, 1, 1);
     case 64: NGCF_DENSE(4, 1, 2);
@@ -335,9 +340,9 @@ extern "C" int64_t ngcf_layer_workspace_bytes(const ngcf_csr_t *c, int d_in, int
 
 extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_t ldEg, const float *Es, int64_t ldEs,
                                     int d_in, const float *W1, const float *b1, const float *W2, const float *b2,
-                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, float *carry,
-                                    int64_t ldc, float *norm, int64_t ldn, void *workspace, int64_t workspace_bytes,
-                                    void *stream)
+                                    int d_out, float leaky, float drop_p, uint64_t drop_seed, const float *drop_mask,
+                                    int64_t ld_mask, float *carry, int64_t ldc, float *norm, int64_t ldn, void *workspace,
+                                    int64_t workspace_bytes, void *stream)
 {
     if (!c) return fail(NGCF_ERR_ARG, "layer_fused: null csr");
     const int64_t need = ngcf_layer_workspace_bytes(c, d_in, d_out);
@@ -356,6 +361,6 @@ extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_
     int rc = ngcf_spmm_csr_f32(c, Eg, ldEg, d_in, LE, ldLE, ws_spmm, spmm_ws, stream);
     if (rc != NGCF_OK) return rc;
     return ngcf_layer_dense_f32(LE, ldLE, Es, ldEs, c->n_rows, d_in, W1, b1, W2, b2, d_out, leaky, drop_p, drop_seed,
-                                carry, ldc, norm, ldn, ws_dense, dense_ws, stream);
+                                drop_mask, ld_mask, carry, ldc, norm, ldn, ws_dense, dense_ws, stream);
 }
 

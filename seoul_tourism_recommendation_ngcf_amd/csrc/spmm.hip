@@ -63,11 +63,52 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
 }
 
 
+// Compact side table of a 1..4-column tail panel: T[c] = {E[c, 0..tail), 0...} as one 16-byte row per table row.  The widths
+// the reference forces on the first layer (65, 130, 515: NGCF.py:39-43) leave 1..3 columns beyond the wide panel; gathered
+// from the strided table each of them costs a 64-byte sector per stored entry (100 M isolated sectors on C3, ~2 ms), from
+// this table (17.6 MB at C3: L2/Infinity-Cache resident) one 16-byte load per entry, 64 entries per wave instruction.
+__global__ void tail_pack_kernel(const float *__restrict__ E, int64_t ldE, int64_t n, int tail, float4 *__restrict__ T)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const float *e = E + r * ldE;
+        float4 t = make_float4(e[0], 0.f, 0.f, 0.f);
+        if (tail > 1) t.y = e[1];
+        if (tail > 2) t.z = e[2];
+        if (tail > 3) t.w = e[3];
+        T[r] = t;
+    }
+}
+
+// the tail product lands in a compact [n_rows, 4] block and is copied into its columns of `out` (which may be a column
+// slice of a wider matrix: nothing beyond the `tail` columns is written)
+__global__ void tail_unpack_kernel(const float4 *__restrict__ T, int64_t n, int tail, float *__restrict__ out, int64_t ldo)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const float4 t = T[r];
+        float *o = out + r * ldo;
+        o[0] = t.x;
+        if (tail > 1) o[1] = t.y;
+        if (tail > 2) o[2] = t.z;
+        if (tail > 3) o[3] = t.w;
+    }
+}
+
+static int64_t tail_table_bytes(const ngcf_csr *c)
+{
+    return align_up(c->n_cols * (int64_t)sizeof(float4), 256) + align_up(c->n_rows * (int64_t)sizeof(float4), 256) + 512;
+}
+
+static int64_t partial_bytes(const ngcf_csr *c, int d)
+{
+    const int64_t n_part = std::max(c->n_seg, c->swept.out.n_seg + c->swept.n_partial);
+    return align_up(n_part * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
+}
+
 extern "C" int64_t ngcf_spmm_workspace_bytes(const ngcf_csr_t *c, int d)
 {
     if (!c || d <= 0) return -1;
-    const int64_t n_part = std::max(c->n_seg, c->swept.out.n_seg + c->swept.n_partial);
-    return align_up(n_part * align_up(d, 4) * (int64_t)sizeof(float), 256) + 256;
+    // [partial sums of the cut rows][compact tail table] - the table sits at the end, the partial sums at the start
+    return partial_bytes(c, d) + tail_table_bytes(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,7 +248,23 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
         if (main > 0) {
             const int rc = spmm_dispatch(c, E, ldE, main, out, ldo, workspace, workspace_bytes, stream, dr);
             if (rc != NGCF_OK) return rc;
-            return spmm_dispatch(c, E + main, ldE, d - main, out + main, ldo, workspace, workspace_bytes, stream, dr);
+            const int tail = d - main;
+            if (tail <= 4 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !getenv("NGCF_NO_TAIL_TABLE")) {
+                // workspace: [partial sums ...            | T_in [n_cols] | T_out [n_rows]]
+                uintptr_t end = reinterpret_cast<uintptr_t>(workspace) + (uintptr_t)workspace_bytes;
+                float4 *Tout = reinterpret_cast<float4 *>((end - (uintptr_t)(c->n_rows * (int64_t)sizeof(float4))) & ~(uintptr_t)255);
+                float4 *Tin = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(Tout) - (uintptr_t)(c->n_cols * (int64_t)sizeof(float4))) &
+                                                         ~(uintptr_t)255);
+                tail_pack_kernel<<<grid_for(c->n_cols, 256), 256, 0, stream>>>(E + main, ldE, c->n_cols, tail, Tin);
+                LAUNCH_CHECK();
+                const int rc2 = spmm_dispatch(c, reinterpret_cast<const float *>(Tin), 4, 4, reinterpret_cast<float *>(Tout), 4, workspace,
+                                              reinterpret_cast<char *>(Tin) - reinterpret_cast<char *>(workspace), stream, dr);
+                if (rc2 != NGCF_OK) return rc2;
+                tail_unpack_kernel<<<grid_for(c->n_rows, 256), 256, 0, stream>>>(Tout, c->n_rows, tail, out + main, ldo);
+                LAUNCH_CHECK();
+                return NGCF_OK;
+            }
+            return spmm_dispatch(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream, dr);
         }
     }
     const int dp = (int)align_up(d, 4);
@@ -215,7 +272,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     const bool with_swept = vec && dr.n == 0 && swept_usable(c, ldE, d);
     float *partial = nullptr;
     if (with_swept ? c->swept.out.n_seg + c->swept.n_partial > 0 : c->n_seg > 0) {
-        const int64_t need = ngcf_spmm_workspace_bytes(c, d);
+        const int64_t need = partial_bytes(c, d);
         if (!workspace || workspace_bytes < need)
             return fail(NGCF_ERR_WORKSPACE, "spmm: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
         partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
@@ -227,7 +284,8 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     if (rc != NGCF_OK) return rc;
     if (vec) {
         const int nq = d / 4;
-        if (nq <= 8) rc = launch_spmm<4, 8, 1, 4>(a);
+        if (nq == 1) rc = launch_spmm<4, 1, 1, 1>(a);          // 16-byte rows (compact tail table): 64 entries per instruction
+        else if (nq <= 8) rc = launch_spmm<4, 8, 1, 4>(a);
         else if (nq <= 16) rc = launch_spmm<4, 16, 1, 8>(a);
         else if (nq <= 32) rc = launch_spmm<4, 32, 1, 8>(a);
         else if (nq <= 64) rc = launch_spmm<4, 64, 1, 8>(a);

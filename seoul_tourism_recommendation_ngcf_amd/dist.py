@@ -4,33 +4,47 @@ The reference is single-device; this is new design (SURVEY.md 8e
 `all_E` are independent given the previous layer's `E`, so the graph is row-partitioned and one exchange
 step per layer moves embeddings between ranks.  Two exchange schemes share the same partition helpers:
 
-``allgather`` (the north-star scheme)
+``allgather`` (the north-star scheme, BASELINE config 4)
     Every rank owns a contiguous user range and a contiguous item range, both cut so that stored entries
-    are balanced (`ngcf_shard_plan`).  Nodes are renumbered into a padded rank-major space
-    (``ShardLayout``) so that ONE `all_gather_into_tensor` per node group drops every rank's freshly
-    computed carry rows straight into the replica the next layer gathers from - no unpack copies.
-    Bytes received per rank and layer: (W-1)/W * N * d * 4.
+    are balanced (`ngcf_shard_plan`).  The user range is cut again into `chunks` row chunks (balanced the same
+    way).  Nodes are renumbered into a padded chunk-major / rank-major space (``ShardLayout``) so that ONE
+    `all_gather_into_tensor` per chunk drops every rank's freshly computed carry rows straight into the replica
+    the next layer gathers from - no unpack copies.  The layer is pipelined: chunk j's kernels are followed at once
+    by chunk j's asynchronous all-gather, which runs on RCCL's stream while chunk j+1 computes; the layer waits
+    only before the next layer's first read.  Bytes received per rank and layer: (W-1)/W * N * d * 4.
 
-``bipartite`` (default: ~10x fewer exchanged bytes)
+``bipartite`` (~10x fewer exchanged bytes)
     `L = [[0, R], [R^T, 0]]` (matrix.py:49-52): user rows only read item embeddings and vice versa.
     Users are partitioned, the (small) item block is replicated.  User rows are then fully local; item
     rows are partial sums over the local users followed by ONE `all_reduce` of `[I, d]` per layer, which
     overlaps with the user-row kernels.  fp32 summation order differs from the single-GPU engine (tolerance,
     not bit-exact); all ranks hold bit-identical item rows because the all-reduce result is.
 
+A rank never holds more of the graph than its own slabs: they are cut from the interaction triplets (host or
+device tensors, `ShardedPropagation.from_interactions`) or from a row-sorted COO (`from_coo`).
+
 Compute is always the HIP engine (`engine.py`); nothing here has a CPU path.  The layout/exchange helpers
 are backend-agnostic tensor plumbing, which is what the world_size-2 `gloo` tests exercise on CPU tensors.
+Forward only: training across ranks (a backward through the exchange) is not built.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
-
+import ctypes as C
 import os
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from . import engine as _eng
+
+SCHEME_NOTES = {
+    "allgather": "row partition (users and items, cut by stored entries) + RCCL all-gather of the carry per layer, user slab "
+                 "pipelined in row chunks (BASELINE config 4)",
+    "bipartite": "users partitioned, item block replicated; item rows = partial sums over local users + one all-reduce of "
+                 "[I, d] per layer (an optimisation beside the north-star scheme: ~10x fewer exchanged bytes)",
+}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -52,42 +66,66 @@ def even_bounds(begin: int, end: int, world: int) -> List[int]:
     return [begin + (n * w) // world for w in range(world + 1)]
 
 
-class ShardLayout:
-    """Padded rank-major numbering of the N = U + I nodes for the all-gather scheme.
+def chunk_bounds(counts: torch.Tensor, rank_bounds: Sequence[int], chunks: int) -> List[int]:
+    """Every rank's range cut again into `chunks` entry-balanced row chunks: W*chunks+1 ascending bounds."""
+    out = [rank_bounds[0]]
+    for r in range(len(rank_bounds) - 1):
+        out += balanced_bounds(counts, rank_bounds[r], rank_bounds[r + 1], chunks)[1:]
+    return out
 
-    Rank r owns users [ub[r], ub[r+1]) and items [ib[r], ib[r+1]) (global node ids; items are U-based).
-    Padded position of rank r's k-th user: r*mu + k; of its k-th item: W*mu + r*mi + k, with mu / mi the
-    largest chunk.  A replica of E in this numbering has P = W*(mu+mi) rows; padding rows are never
-    referenced by any column index.
+
+class ShardLayout:
+    """Padded numbering of the N = U + I nodes for the all-gather scheme.
+
+    Rank r owns users [ub[r], ub[r+1]) and items [ib[r], ib[r+1]) (global node ids; items are U-based); its user
+    range is cut into C chunks [cb[r*C+j], cb[r*C+j+1]).  Padded position of the k-th user of chunk j of rank r:
+    j*W*mc + r*mc + k (chunk-major, then rank-major: the region of chunk j is what ONE all-gather of that chunk
+    fills); of rank r's k-th item: W*C*mc + r*mi + k, with mc / mi the largest user chunk / item range.  A replica of E
+    in this numbering has P = W*(C*mc + mi) rows; padding rows are never referenced by any column index.
+    With C = 1 this is the plain rank-major layout.
     """
 
-    def __init__(self, n_user: int, n_item: int, user_bounds: Sequence[int], item_bounds: Sequence[int]):
+    def __init__(self, n_user: int, n_item: int, user_bounds: Sequence[int], item_bounds: Sequence[int],
+                 user_chunk_bounds: Optional[Sequence[int]] = None):
         assert len(user_bounds) == len(item_bounds) and user_bounds[0] == 0 and user_bounds[-1] == n_user
         assert item_bounds[0] == n_user and item_bounds[-1] == n_user + n_item
         self.n_user, self.n_item = n_user, n_item
         self.world = len(user_bounds) - 1
         self.ub, self.ib = list(user_bounds), list(item_bounds)
-        self.mu = max(max(self.ub[r + 1] - self.ub[r] for r in range(self.world)), 1)
+        self.cb = list(user_chunk_bounds) if user_chunk_bounds is not None else list(user_bounds)
+        assert (len(self.cb) - 1) % self.world == 0
+        self.chunks = (len(self.cb) - 1) // self.world
+        assert [self.cb[r * self.chunks] for r in range(self.world + 1)] == self.ub, "chunk bounds must refine the rank bounds"
+        assert all(a <= b for a, b in zip(self.cb, self.cb[1:]))
+        self.mc = max(max(b - a for a, b in zip(self.cb, self.cb[1:])), 1)
+        self.mu = self.mc                                         # (name kept for the one-chunk layout)
         self.mi = max(max(self.ib[r + 1] - self.ib[r] for r in range(self.world)), 1)
-        self.P = self.world * (self.mu + self.mi)
+        self.n_user_pos = self.world * self.chunks * self.mc
+        self.P = self.n_user_pos + self.world * self.mi
 
-    def n_users_of(self, r): return self.ub[r + 1] - self.ub[r]
+    def n_users_of(self, r, j=None):
+        if j is None:
+            return self.ub[r + 1] - self.ub[r]
+        return self.cb[r * self.chunks + j + 1] - self.cb[r * self.chunks + j]
+
     def n_items_of(self, r): return self.ib[r + 1] - self.ib[r]
-    def user_pos(self, r): return r * self.mu
-    def item_pos(self, r): return self.world * self.mu + r * self.mi
+    def user_pos(self, r, j=0): return (j * self.world + r) * self.mc
+    def item_pos(self, r): return self.n_user_pos + r * self.mi
+    def chunk_region(self, j): return j * self.world * self.mc, (j + 1) * self.world * self.mc
+    def chunk_range(self, r, j): return self.cb[r * self.chunks + j], self.cb[r * self.chunks + j + 1]
 
     def to_padded(self, node: torch.Tensor) -> torch.Tensor:
         """Global node id -> padded position (vectorised)."""
         dev = node.device
-        ub = torch.tensor(self.ub, device=dev)
+        cb = torch.tensor(self.cb, device=dev)
         ib = torch.tensor(self.ib, device=dev)
         is_item = node >= self.n_user
-        ru = torch.searchsorted(ub, node, right=True) - 1
-        ri = torch.searchsorted(ib, node, right=True) - 1
-        ru = ru.clamp(0, self.world - 1)
-        ri = ri.clamp(0, self.world - 1)
-        pu = ru * self.mu + (node - ub[ru])
-        pi = self.world * self.mu + ri * self.mi + (node - ib[ri])
+        # empty chunks repeat a bound: right=True picks the last chunk that starts at or before the node, the one holding it
+        ci = (torch.searchsorted(cb, node, right=True) - 1).clamp(0, self.world * self.chunks - 1)
+        ri = (torch.searchsorted(ib, node, right=True) - 1).clamp(0, self.world - 1)
+        r, j = ci // self.chunks, ci % self.chunks
+        pu = (j * self.world + r) * self.mc + (node - cb[ci])
+        pi = self.n_user_pos + ri * self.mi + (node - ib[ri])
         return torch.where(is_item, pi, pu)
 
     def owner_of_user(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -109,11 +147,39 @@ def slab_coo(rows, cols, vals, lo: int, hi: int):
     return rows[a:b] - lo, cols[a:b], vals[a:b]
 
 
-def allgather_rows(full_block: torch.Tensor, send: torch.Tensor, group=None):
+def laplacian_values(u: torch.Tensor, i: torch.Tensor, w: torch.Tensor, n_user: int, n_item: int):
+    """Values of the symmetric-normalised Laplacian for the interaction triplets, the way `Matrix.create_matrix` forms
+    them (matrix.py:55-62: count degrees, d^-1/2 in float32, product in float64, cast to float32); also the degrees."""
+    deg_u = torch.bincount(u, minlength=n_user)
+    deg_i = torch.bincount(i, minlength=n_item)
+    ds_u = deg_u.to(torch.float32).pow(-0.5)
+    ds_i = deg_i.to(torch.float32).pow(-0.5)
+    ds_u[torch.isinf(ds_u)] = 0
+    ds_i[torch.isinf(ds_i)] = 0
+    return (ds_u[u].double() * w.double() * ds_i[i].double()).float(), deg_u, deg_i
+
+
+def cut_slabs(u: torch.Tensor, i: torch.Tensor, v: torch.Tensor, n_user: int, user_lo: int, user_hi: int,
+              item_lo: int, item_hi: int):
+    """This rank's part of L = [[0, R], [R^T, 0]] from the interaction triplets sorted by (u, i) with Laplacian values v:
+    the user rows [user_lo, user_hi) (a contiguous slice of the triplets) and the item rows [item_lo, item_hi) (item
+    INDICES, a masked selection re-sorted by (i, u)).  Returns two (rows, cols, vals) triplets with GLOBAL node ids,
+    row-sorted, entries inside a row in ascending column order - the same entries and order as the matching rows of
+    the full COO of `graphs._normalise`, without ever forming it."""
+    a, b = (int(x) for x in torch.searchsorted(u, torch.tensor([user_lo, user_hi], device=u.device)))
+    user_rows = (u[a:b], i[a:b] + n_user, v[a:b])
+    sel = (i >= item_lo) & (i < item_hi)
+    iu, ii, iv = u[sel], i[sel], v[sel]
+    order = torch.sort(ii, stable=True).indices           # (u, i) order -> (i, u) order
+    item_rows = (ii[order] + n_user, iu[order], iv[order])
+    return user_rows, item_rows
+
+
+def allgather_rows(full_block: torch.Tensor, send: torch.Tensor, group=None, async_op: bool = False):
     """full_block[W*m, d] <- every rank's send[m, d], rank-major (one collective, no unpack)."""
     assert full_block.is_contiguous() and send.is_contiguous()
     assert full_block.shape[0] == send.shape[0] * dist.get_world_size(group)
-    dist.all_gather_into_tensor(full_block, send, group=group)
+    return dist.all_gather_into_tensor(full_block, send, group=group, async_op=async_op)
 
 
 def owner_rows_sum(local_rows: torch.Tensor, owned: torch.Tensor, group=None) -> torch.Tensor:
@@ -124,63 +190,131 @@ def owner_rows_sum(local_rows: torch.Tensor, owned: torch.Tensor, group=None) ->
     return out
 
 
+class _CabiAllGather:
+    """`ngcf_allgather_rows` (include/ngcf_hip.h): ncclAllGather on a communicator handle, issued by the library on a
+    stream of its own.  Opt-in (NGCF_DIST_COLLECTIVES=cabi, backend "nccl" only): the handle is the process group's own
+    RCCL communicator.  The default path is `torch.distributed`'s all_gather_into_tensor, which does the same thing."""
+
+    def __init__(self, group, device):
+        pg = group if group is not None else dist.group.WORLD
+        backend = pg._get_backend(torch.device(device))
+        dist.barrier(group=group)                                  # the communicator exists after the first collective
+        self.comm = C.c_void_p(int(backend._comm_ptr()))
+        self.stream = torch.cuda.Stream(device=device)
+
+    def __call__(self, full_block: torch.Tensor, send: torch.Tensor):
+        cur = torch.cuda.current_stream(send.device)
+        self.stream.wait_stream(cur)                               # the rows were produced on the compute stream
+        _lib.check(_lib.load().ngcf_allgather_rows(self.comm, C.c_void_p(send.data_ptr()), C.c_void_p(full_block.data_ptr()),
+                                                   send.shape[0], send.shape[1], C.c_void_p(self.stream.cuda_stream)))
+        send.record_stream(self.stream)
+        full_block.record_stream(self.stream)
+        return self
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 # ------------------------------------------------------------------------------------------------
 # sharded propagation on the HIP engine
 # ------------------------------------------------------------------------------------------------
 class ShardedPropagation:
     """NGCF.py:120-156 over `world` GPUs for one Laplacian slice.
 
-    `coo` is the FULL row-sorted COO of the [N, N] Laplacian on this rank's device (every rank builds or
-    loads the same one and keeps only its part).  Parameters are replicated: pass the same `NGCF` module
-    (same seed / same state_dict) on every rank.
+    Build with `from_interactions` (this rank keeps only its slabs; the triplets may live on the host) or `from_coo`
+    (a row-sorted COO of the [N, N] Laplacian: tests and small graphs).  Parameters are replicated: pass the same `NGCF`
+    module (same seed / same state_dict) on every rank.
     """
 
     def __init__(self, model, rows: torch.Tensor, cols: torch.Tensor, vals: torch.Tensor,
-                 mode: str = "bipartite", group=None):
+                 mode: str = "allgather", group=None, chunks: Optional[int] = None):
+        """From the FULL row-sorted COO (every rank builds or loads the same one and keeps only its part)."""
+        U, I = model.n_user, model.n_item
+        n_ue = int(torch.searchsorted(rows, torch.tensor([U], device=rows.device)))
+        if n_ue and (int(cols[:n_ue].min()) < U or (n_ue < rows.numel() and int(cols[n_ue:].max()) >= U)):
+            raise RuntimeError("the sharded engine needs L = [[0, R], [R^T, 0]] (matrix.py:49-52)")
+        if n_ue * 2 != rows.numel():
+            raise RuntimeError("the sharded engine needs both triangles of L stored (matrix.py:51-52)")
+        cnt = row_counts(rows, U + I)
+
+        def cut(user_lo, user_hi, item_lo, item_hi):
+            a = slab_coo(rows, cols, vals, user_lo, user_hi)
+            b = slab_coo(rows, cols, vals, U + item_lo, U + item_hi)
+            return (a[0] + user_lo, a[1], a[2]), (b[0] + U + item_lo, b[1], b[2])
+        self._setup(model, cnt[:U], cnt[U:], cut, mode, group, chunks, rows.device)
+
+    @classmethod
+    def from_coo(cls, model, rows, cols, vals, mode: str = "allgather", group=None, chunks: Optional[int] = None):
+        return cls(model, rows, cols, vals, mode, group, chunks)
+
+    @classmethod
+    def from_interactions(cls, model, u: torch.Tensor, i: torch.Tensor, w: torch.Tensor, mode: str = "allgather",
+                          group=None, chunks: Optional[int] = None, device=None):
+        """From the unique interaction triplets (u, i, w) sorted by (u, i), on any device (host tensors included): the
+        degrees and the Laplacian values are formed where the triplets live, and only this rank's slabs - about 2/W of
+        the stored entries - reach the compute device.  The doubled [N, N] COO is never materialised."""
+        self = cls.__new__(cls)
+        v, deg_u, deg_i = laplacian_values(u, i, w, model.n_user, model.n_item)
+        self._setup(model, deg_u, deg_i, lambda ul, uh, il, ih: cut_slabs(u, i, v, model.n_user, ul, uh, il, ih),
+                    mode, group, chunks, device if device is not None else model._dev())
+        return self
+
+    def _setup(self, model, deg_u, deg_i, cut, mode, group, chunks, dev):
         assert mode in ("bipartite", "allgather")
         self.model, self.mode, self.group = model, mode, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.U, self.I = model.n_user, model.n_item
         self.N = self.U + self.I
-        dev = rows.device
-        self.dev = dev
+        self.dev = dev = torch.device(dev)
         self.ws = _eng.Workspace()
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         U, I, W, r = self.U, self.I, self.world, self.rank
-        n_user_entries = int(torch.searchsorted(rows, torch.tensor([U], device=dev)))
+        swept_mode = int(os.environ.get("NGCF_SPMM_MODE", "3"))
+        to_dev = lambda t: t.to(dev, non_blocking=True)            # noqa: E731
         if mode == "bipartite":
-            if n_user_entries and (int(cols[:n_user_entries].min()) < U or int(cols[n_user_entries:].max()) >= U):
-                raise RuntimeError("bipartite exchange needs L = [[0, R], [R^T, 0]] (matrix.py:49-52)")
             self.ub = even_bounds(0, U, W)
             lo, hi = self.ub[r], self.ub[r + 1]
             self.nu = hi - lo
+            (ur, uc, uv), _ = cut(lo, hi, 0, 0)
+            ur, uc, uv = to_dev(ur), to_dev(uc), to_dev(uv)
             # user rows: local users x all items (columns renumbered to item ids)
-            ur, uc, uv = slab_coo(rows, cols, vals, lo, hi)
-            self.csr_u = _eng.LaplacianCSR.from_coo(ur, uc - U, uv, self.nu, I)
-            # item rows restricted to local user columns -> partial sums
-            ir, ic, iv = rows[n_user_entries:] - U, cols[n_user_entries:], vals[n_user_entries:]
-            sel = (ic >= lo) & (ic < hi)
-            self.csr_it = _eng.LaplacianCSR.from_coo(ir[sel], ic[sel] - lo, iv[sel], I, max(self.nu, 1))
+            self.csr_u = _eng.LaplacianCSR.from_coo(ur - lo, uc - U, uv, self.nu, I)
+            # item rows restricted to local user columns -> partial sums: the transpose of the same slice
+            order = torch.sort(uc, stable=True).indices
+            self.csr_it = _eng.LaplacianCSR.from_coo(uc[order] - U, ur[order] - lo, uv[order], I, max(self.nu, 1))
             # the item partial sums run alone on the GPU (the all-reduce starts after them): L2-swept kernel where it
             # pays.  The user rows overlap with the all-reduce; a persistent one-workgroup-per-CU kernel must not
             # share the CUs with the collective's kernels, so they stay on the row-wise kernels.
-            self.csr_it.set_mode(int(os.environ.get("NGCF_SPMM_MODE", "3")))
+            self.csr_it.set_mode(swept_mode)
             self.local_nnz = self.csr_u.nnz + self.csr_it.nnz
         else:
-            cnt = row_counts(rows, self.N)
+            cnt = torch.cat([deg_u.to("cpu", torch.int64), deg_i.to("cpu", torch.int64)])
             ub = balanced_bounds(cnt, 0, U, W)
             ib = balanced_bounds(cnt, U, self.N, W)
-            self.layout = ShardLayout(U, I, ub, ib)
-            lay = self.layout
-            pc = lay.to_padded(cols)
-            ur, uc, uv = slab_coo(rows, pc, vals, ub[r], ub[r + 1])
-            ir, ic, iv = slab_coo(rows, pc, vals, ib[r], ib[r + 1])
+            if chunks is None:      # pipeline depth of the user slab; one chunk when there is nobody to exchange with
+                chunks = int(os.environ.get("NGCF_DIST_CHUNKS", "4")) if W > 1 else 1
+            self.chunks = chunks = max(1, int(chunks))
+            self.layout = lay = ShardLayout(U, I, ub, ib, chunk_bounds(cnt, ub, chunks))
+            (ur, uc, uv), (ir, ic, iv) = cut(ub[r], ub[r + 1], ib[r] - U, ib[r + 1] - U)
+            ur, uc, uv, ir, ic, iv = (to_dev(t) for t in (ur, uc, uv, ir, ic, iv))
             self.nu, self.ni = lay.n_users_of(r), lay.n_items_of(r)
-            self.csr_u = _eng.LaplacianCSR.from_coo(ur, uc, uv, self.nu, lay.P)
-            self.csr_i = _eng.LaplacianCSR.from_coo(ir, ic, iv, self.ni, lay.P)
-            self.csr_i.set_mode(int(os.environ.get("NGCF_SPMM_MODE", "3")))   # runs with no collective in flight (see above)
-            self.local_nnz = self.csr_u.nnz + self.csr_i.nnz
+            self.csr_u = []                                        # one CSR per row chunk of the user slab
+            for j in range(chunks):
+                lo, hi = lay.chunk_range(r, j)
+                cr, cc, cv = slab_coo(ur, uc, uv, lo, hi)
+                self.csr_u.append(_eng.LaplacianCSR.from_coo(cr, lay.to_padded(cc), cv, hi - lo, lay.P))
+            self.csr_i = _eng.LaplacianCSR.from_coo(ir - ib[r], lay.to_padded(ic), iv, self.ni, lay.P)
+            # the item slab runs with no collective in flight (the layer's gathers have all been waited for): swept kernel
+            # where it pays.  With one chunk and one rank nothing overlaps the user slab either.
+            self.csr_i.set_mode(swept_mode)
+            if W == 1:
+                for c in self.csr_u:
+                    c.set_mode(swept_mode)
+            self.local_nnz = sum(c.nnz for c in self.csr_u) + self.csr_i.nnz
         self._bufs = {}
+        self._cabi = None
+        if os.environ.get("NGCF_DIST_COLLECTIVES") == "cabi" and dist.get_backend(group) == "nccl":
+            self._cabi = _CabiAllGather(group, dev)
 
     def _buf(self, name, shape):
         b = self._bufs.get(name)
@@ -193,6 +327,18 @@ class ShardedPropagation:
         m = self.model
         return ([l.weight.detach() for l in m.w1_list], [l.bias.detach() for l in m.w1_list],
                 [l.weight.detach() for l in m.w2_list], [l.bias.detach() for l in m.w2_list])
+
+    def spmm_shapes(self):
+        """(nnz, rows, cols) of this rank's SpMM launches of one layer (for the roofline's algorithmic bytes)."""
+        if self.mode == "bipartite":
+            cs = [self.csr_it, self.csr_u]
+        else:
+            cs = [self.csr_i] + list(self.csr_u)
+        return [(c.nnz, c.n_rows, c.n_cols) for c in cs]
+
+    def swept_rows(self):
+        cs = [self.csr_it, self.csr_u] if self.mode == "bipartite" else [self.csr_i] + list(self.csr_u)
+        return [c.swept_rows for c in cs]
 
     # -- propagation ----------------------------------------------------------------------------
     def propagate(self):
@@ -231,8 +377,13 @@ class ShardedPropagation:
         self.allE_u, self.allE_i = allE_u, allE_i
         return allE_u, allE_i
 
+    def _gather_async(self, region: torch.Tensor, send: torch.Tensor):
+        if self._cabi is not None:
+            return self._cabi(region, send)
+        return allgather_rows(region, send, self.group, async_op=True)
+
     def _propagate_allgather(self):
-        m, lay, r, W = self.model, self.layout, self.rank, self.world
+        m, lay, r, W, Cn = self.model, self.layout, self.rank, self.world, self.chunks
         w1, b1, w2, b2 = self._params()
         widths = [m.emb_size] + [int(w.shape[0]) for w in w1]
         D, n_layer = sum(widths), len(w1)
@@ -246,33 +397,39 @@ class ShardedPropagation:
         # layer-0 replica from the replicated parameter tables: local copies, no communication
         full = self._buf(("full", 0), (lay.P, d0))
         for q in range(W):
-            if lay.n_users_of(q):
-                _eng.copy_rows(uw[lay.ub[q]:lay.ub[q + 1]], full[lay.user_pos(q):lay.user_pos(q) + lay.n_users_of(q)])
+            for j in range(Cn):
+                lo, hi = lay.chunk_range(q, j)
+                if hi > lo:
+                    _eng.copy_rows(uw[lo:hi], full[lay.user_pos(q, j):lay.user_pos(q, j) + hi - lo])
             if lay.n_items_of(q):
                 _eng.copy_rows(iw[lay.ib[q] - self.U:lay.ib[q + 1] - self.U],
                                full[lay.item_pos(q):lay.item_pos(q) + lay.n_items_of(q)])
         off = d0
+        first_row = [lay.chunk_range(r, j)[0] - lay.ub[r] for j in range(Cn)]      # chunk j's rows inside allE_u
         for k in range(n_layer):
             d_out = widths[k + 1]
             last = k == n_layer - 1
-            su = None if last else self._buf(("su", k % 2), (lay.mu, d_out))
+            nxt = None if last else self._buf(("full", (k + 1) % 2 + 1), (lay.P, d_out))
+            works = []
+            # item slab first, alone on the GPU; its (small) all-gather overlaps with the first user chunk
             si = None if last else self._buf(("si", k % 2), (lay.mi, d_out))
-            e_u = full[lay.user_pos(r):lay.user_pos(r) + nu]
-            e_i = full[lay.item_pos(r):lay.item_pos(r) + ni]
-            # item slab first: its (small) all-gather then overlaps with the user slab's kernels
-            _eng.layer_fused(self.csr_i, full, e_i, w1[k], b1[k], w2[k], b2[k], None if last else si[:ni],
-                             allE_i[:, off:off + d_out], self.ws)
-            nxt = None
-            wi = None
+            _eng.layer_fused(self.csr_i, full, full[lay.item_pos(r):lay.item_pos(r) + ni], w1[k], b1[k], w2[k], b2[k],
+                             None if last else si[:ni], allE_i[:, off:off + d_out], self.ws)
             if not last:
-                nxt = self._buf(("full", (k + 1) % 2 + 1), (lay.P, d_out))
-                wi = dist.all_gather_into_tensor(nxt[W * lay.mu:], si, group=self.group, async_op=True)
-            _eng.layer_fused(self.csr_u, full, e_u, w1[k], b1[k], w2[k], b2[k], None if last else su[:nu],
-                             allE_u[:, off:off + d_out], self.ws)
+                works.append(self._gather_async(nxt[lay.n_user_pos:], si))
+            # user slab, chunk by chunk: chunk j's all-gather is in flight while chunk j+1 computes
+            for j in range(Cn):
+                n_j = lay.n_users_of(r, j)
+                sj = None if last else self._buf(("su", k % 2, j), (lay.mc, d_out))
+                pos = lay.user_pos(r, j)
+                _eng.layer_fused(self.csr_u[j], full, full[pos:pos + n_j], w1[k], b1[k], w2[k], b2[k],
+                                 None if last else sj[:n_j], allE_u[first_row[j]:first_row[j] + n_j, off:off + d_out], self.ws)
+                if not last:
+                    a, b = lay.chunk_region(j)
+                    works.append(self._gather_async(nxt[a:b], sj))
+            for wk in works:                                       # only now: the next layer reads the whole replica
+                wk.wait()
             if not last:
-                wu = dist.all_gather_into_tensor(nxt[:W * lay.mu], su, group=self.group, async_op=True)
-                wi.wait()
-                wu.wait()
                 full = nxt
             off += d_out
         self.allE_u, self.allE_i = allE_u, allE_i

@@ -187,8 +187,9 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
 
 def layer_fused(csr: LaplacianCSR, E_gather: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2,
                 carry: Optional[torch.Tensor], norm: torch.Tensor, ws: Workspace,
-                drop_p: float = 0.0, drop_seed: int = 0):
-    """One propagation layer (NGCF.py:130-146) through ngcf_layer_fused_f32."""
+                drop_p: float = 0.0, drop_seed: int = 0, drop_mask: Optional[torch.Tensor] = None):
+    """One propagation layer (NGCF.py:130-146) through ngcf_layer_fused_f32.  `drop_mask` [n_rows, d_out]: the noise
+    tensor of nn.Dropout (0 or 1/(1-p)) drawn by the caller; None with drop_p > 0: the in-kernel hash stream."""
     lib = _lib.load()
     d_in, d_out = int(W1.shape[1]), int(W1.shape[0])
     for t, nm in ((E_gather, "E_gather"), (E_self, "E_self"), (W1, "W1"), (b1, "b1"), (W2, "W2"), (b2, "b2"), (norm, "norm")):
@@ -204,12 +205,13 @@ def layer_fused(csr: LaplacianCSR, E_gather: torch.Tensor, E_self: torch.Tensor,
         _lib.check(lib.ngcf_layer_fused_f32(
             csr._h, _ptr(E_gather), _row_major_ld(E_gather, "E_gather"), _ptr(E_self), _row_major_ld(E_self, "E_self"),
             d_in, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), d_out, LEAKY_SLOPE, float(drop_p), int(drop_seed),
+            _ptr(drop_mask), 0 if drop_mask is None else _row_major_ld(drop_mask, "drop_mask"),
             _ptr(carry), 0 if carry is None else _row_major_ld(carry, "carry"),
             _ptr(norm), _row_major_ld(norm, "norm"), _ptr(w), w.numel(), _stream()))
 
 
 def layer_dense(LE: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2, carry, norm, ws: Workspace,
-                drop_p: float = 0.0, drop_seed: int = 0):
+                drop_p: float = 0.0, drop_seed: int = 0, drop_mask: Optional[torch.Tensor] = None):
     """Dense half of a layer (NGCF.py:131-146) on an existing LE, through ngcf_layer_dense_f32."""
     lib = _lib.load()
     d_in, d_out = int(W1.shape[1]), int(W1.shape[0])
@@ -222,6 +224,7 @@ def layer_dense(LE: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2, carry, n
         _lib.check(lib.ngcf_layer_dense_f32(
             _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E_self), _row_major_ld(E_self, "E_self"), LE.shape[0], d_in,
             _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), d_out, LEAKY_SLOPE, float(drop_p), int(drop_seed),
+            _ptr(drop_mask), 0 if drop_mask is None else _row_major_ld(drop_mask, "drop_mask"),
             _ptr(carry), 0 if carry is None else _row_major_ld(carry, "carry"),
             _ptr(norm), _row_major_ld(norm, "norm"), _ptr(w), w.numel(), _stream()))
 

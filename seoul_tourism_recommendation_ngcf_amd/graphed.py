@@ -19,6 +19,16 @@ from . import engine as _eng
 from .autograd import propagate_forward
 
 
+class _Buffers:
+    """What `propagate_forward` keeps on its `owner` between calls (workspace, carry ping-pong, padded E0).  The graph
+    bakes their addresses in, so it owns a private set: an eager call on the same module (another year slice, a backward
+    pass) may grow or replace the module's own buffers without touching anything a replay writes through."""
+
+    def __init__(self):
+        self._ws = _eng.Workspace()
+        self._carry = [None, None]
+
+
 class GraphedForward:
     def __init__(self, model, batch_size: int, year_idx: int = 0, with_neg: bool = True):
         if model.training:
@@ -30,8 +40,10 @@ class GraphedForward:
         self.dev = dev
         z = lambda: torch.zeros(self.B, dtype=torch.int64, device=dev)  # noqa: E731
         self.inputs = {k: z() for k in ("u_id", "age", "sex", "month", "day", "dow", "pos_item", "neg_item")}
-        self.csr = model.laplacian_csr(self.year_idx)      # built (and planned) outside the capture
-        self.status = model._status_buf(dev)
+        self.csr = model.laplacian_csr(self.year_idx)      # built (and planned) outside the capture; kept alive here
+        self.bufs = _Buffers()
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = torch.full((model.n_user,), -1, dtype=torch.int32, device=dev)
         # the weights the injection overwrites must look the same at capture time as before it
         saved = model.user_embedding.weight.data[:1].clone()
         side = torch.cuda.Stream(device=dev)
@@ -47,6 +59,7 @@ class GraphedForward:
         torch.cuda.synchronize(dev)
         model.user_embedding.weight.data[:1].copy_(saved)  # row 0 was injected with the all-zero warm-up batch
         self.status.zero_()
+        self._baked = self._baked_pointers()
 
     def _body(self):
         m, i = self.model, self.inputs
@@ -55,9 +68,9 @@ class GraphedForward:
                                 (m.age_emb.weight.data, m.sex_emb.weight.data, m.month_emb.weight.data,
                                  m.day_emb.weight.data, m.dow_emb.weight.data),
                                 (i["age"], i["sex"], i["month"], i["day"], i["dow"]), i["u_id"], m.emb_ratio,
-                                m._scratch_buf(self.dev), self.status)
+                                self.scratch, self.status)
             w1, b1, w2, b2 = m._layer_params()
-            all_E = propagate_forward(m, [self.csr] * m.n_layer, m.user_embedding.weight, m.item_embedding.weight,
+            all_E = propagate_forward(self.bufs, [self.csr] * m.n_layer, m.user_embedding.weight, m.item_embedding.weight,
                                       w1, b1, w2, b2, [0.0] * m.n_layer, [0] * m.n_layer)
             users, items = all_E[:m.n_user], all_E[m.n_user:]
             u = _eng.gather_rows(users, i["u_id"], self.status)
@@ -80,9 +93,16 @@ class GraphedForward:
             self.inputs[k].copy_(v, non_blocking=True)
         return self.replay()
 
+    def _baked_pointers(self):
+        b = self.bufs
+        return tuple(t.data_ptr() for t in (b._ws.buf, b._carry[0], b._carry[1], getattr(b, "_e0_pad", None), self.scratch,
+                                            self.status) if t is not None)
+
     def replay(self):
         """Replay on whatever `self.inputs[...]` (the graph's static int64 index buffers) hold: callers that write their
         batches straight into those buffers save the eight small copies of `__call__`."""
+        if self._baked_pointers() != self._baked:
+            raise RuntimeError("GraphedForward: a buffer baked into the captured graph was replaced; capture again")
         self.graph.replay()
         all_E, u, p, n = self.out
         m = self.model

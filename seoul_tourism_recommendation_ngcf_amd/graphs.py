@@ -31,9 +31,9 @@ def _normalise(u: torch.Tensor, i: torch.Tensor, w: torch.Tensor, n_user: int, n
     return {"rows": rows, "cols": cols, "vals": vals}
 
 
-def synthetic_bipartite(n_user: int, n_item: int, n_inter: int, seed: int, device, item_skew: bool = True):
-    """SURVEY.md 8d C3/C5 generator: u ~ Uniform, i = floor(I * r^2) (popularity skew), de-duplicated,
-    weights U(0.5, 5.0), count-degree normalisation.  Returns row-sorted COO + sizes (nnz = 2 x interactions)."""
+def synthetic_interactions(n_user: int, n_item: int, n_inter: int, seed: int, device, item_skew: bool = True):
+    """SURVEY.md 8d C3/C5 generator: u ~ Uniform, i = floor(I * r^2) (popularity skew), de-duplicated, weights
+    U(0.5, 5.0).  Returns the unique interaction triplets (u, i, w) sorted by (u, i)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     u = torch.randint(0, n_user, (n_inter,), generator=g, device=device, dtype=torch.int64)
@@ -46,6 +46,12 @@ def synthetic_bipartite(n_user: int, n_item: int, n_inter: int, seed: int, devic
     u, i = key // n_item, key % n_item
     del key
     w = torch.rand((u.numel(),), generator=g, device=device, dtype=torch.float32) * 4.5 + 0.5
+    return u, i, w
+
+
+def synthetic_bipartite(n_user: int, n_item: int, n_inter: int, seed: int, device, item_skew: bool = True):
+    """The same graph as the row-sorted COO of its count-degree normalised Laplacian + sizes (nnz = 2 x interactions)."""
+    u, i, w = synthetic_interactions(n_user, n_item, n_inter, seed, device, item_skew)
     coo = _normalise(u, i, w, n_user, n_item)
     coo.update({"n_user": n_user, "n_item": n_item, "interactions": int(u.numel()), "nnz": int(2 * u.numel())})
     return coo

@@ -67,37 +67,61 @@ def _cpu_worker(rank, world, port, ret):
         L = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (N, N))
         want = orc.propagate_torch(L, E0[:U], E0[U:], w1, b1, w2, b2)
 
-        # ---- all-gather scheme: padded rank-major layout, one collective per node group and layer
-        cnt = nd.row_counts(rows, N)
+        # ---- all-gather scheme: padded chunk-major / rank-major layout, the user slab pipelined in 3 row chunks, every
+        # chunk's asynchronous all-gather issued right after the chunk (dist._propagate_allgather does exactly this);
+        # the slabs are cut from the interaction triplets, never from the doubled COO
+        from seoul_tourism_recommendation_ngcf_amd import graphs
+        iu, ii, iw = graphs.synthetic_interactions(U, I, 3000, seed=5, device="cpu")
+        iv, deg_u, deg_i = nd.laplacian_values(iu, ii, iw, U, I)
+        cnt = torch.cat([deg_u, deg_i])
+        assert torch.equal(cnt, nd.row_counts(rows, N))
         ub = nd.balanced_bounds(cnt, 0, U, world)
         ib = nd.balanced_bounds(cnt, U, N, world)
-        lay = nd.ShardLayout(U, I, ub, ib)
-        pc = lay.to_padded(cols)
-        assert torch.equal(torch.sort(lay.to_padded(torch.arange(N))).values.unique(), torch.sort(lay.to_padded(torch.arange(N))).values)
+        C = 3
+        lay = nd.ShardLayout(U, I, ub, ib, nd.chunk_bounds(cnt, ub, C))
+        assert lay.chunks == C and lay.P == world * (C * lay.mc + lay.mi)
+        pos_all = lay.to_padded(torch.arange(N))
+        assert pos_all.unique().numel() == N and int(pos_all.max()) < lay.P
+        (sur, suc, suv), (sir, sic, siv) = nd.cut_slabs(iu, ii, iv, U, ub[rank], ub[rank + 1], ib[rank] - U, ib[rank + 1] - U)
+        for (a_, b_, c_), (lo_, hi_) in (((sur, suc, suv), (ub[rank], ub[rank + 1])), ((sir, sic, siv), (ib[rank], ib[rank + 1]))):
+            r_, c2_, v_ = nd.slab_coo(rows, cols, vals, lo_, hi_)           # the same rows of the full COO, entry for entry
+            assert torch.equal(a_ - lo_, r_) and torch.equal(b_, c2_) and torch.equal(c_, v_)
         full = torch.full((lay.P, d0), float("nan"))
-        for q in range(world):
-            full[lay.user_pos(q):lay.user_pos(q) + lay.n_users_of(q)] = E0[ub[q]:ub[q + 1]]
-            full[lay.item_pos(q):lay.item_pos(q) + lay.n_items_of(q)] = E0[ib[q]:ib[q + 1]]
+        full[pos_all] = E0
         nu, ni = lay.n_users_of(rank), lay.n_items_of(rank)
         blocks_u, blocks_i = [E0[ub[rank]:ub[rank + 1]]], [E0[ib[rank]:ib[rank + 1]]]
+
+        def slab_layer(r_, c_, v_, lo, hi, pos, m, k):
+            n_own = hi - lo
+            Ls = torch.sparse_coo_tensor(torch.stack([r_ - lo, lay.to_padded(c_)]), v_, (n_own, lay.P))
+            table = torch.nan_to_num(full, nan=0.0)               # padding rows are never referenced
+            carry, nrm = _dense_oracle(torch.mm(Ls, table), full[pos:pos + n_own], w1[k], b1[k], w2[k], b2[k])
+            send = torch.full((m, carry.shape[1]), float("nan"))
+            send[:n_own] = carry
+            return send, nrm
+
         for k in range(len(layers)):
-            outs = []
-            for (lo, hi, pos, n_own, m) in ((ub[rank], ub[rank + 1], lay.user_pos(rank), nu, lay.mu),
-                                            (ib[rank], ib[rank + 1], lay.item_pos(rank), ni, lay.mi)):
-                r_, c_, v_ = nd.slab_coo(rows, pc, vals, lo, hi)
-                Ls = torch.sparse_coo_tensor(torch.stack([r_, c_]), v_, (n_own, lay.P))
-                table = torch.nan_to_num(full, nan=0.0)           # padding rows are never referenced
-                LE = torch.mm(Ls, table)
-                carry, nrm = _dense_oracle(LE, full[pos:pos + n_own], w1[k], b1[k], w2[k], b2[k])
-                send = torch.full((m, carry.shape[1]), float("nan"))
-                send[:n_own] = carry
-                outs.append((send, nrm))
-            nxt = torch.empty((lay.P, outs[0][0].shape[1]))
-            nd.allgather_rows(nxt[:world * lay.mu], outs[0][0])
-            nd.allgather_rows(nxt[world * lay.mu:], outs[1][0])
-            blocks_u.append(outs[0][1])
-            blocks_i.append(outs[1][1])
+            nxt = torch.full((lay.P, layers[k]), float("nan"))
+            works, keep = [], []
+            send, nrm_i = slab_layer(sir, sic, siv, ib[rank], ib[rank + 1], lay.item_pos(rank), lay.mi, k)
+            works.append(nd.allgather_rows(nxt[lay.n_user_pos:], send, async_op=True))
+            keep.append(send)
+            nrm_u = []
+            for j in range(C):
+                lo, hi = lay.chunk_range(rank, j)
+                a, b = (int(x) for x in torch.searchsorted(sur, torch.tensor([lo, hi])))
+                send, nrm = slab_layer(sur[a:b], suc[a:b], suv[a:b], lo, hi, lay.user_pos(rank, j), lay.mc, k)
+                ra, rb = lay.chunk_region(j)
+                works.append(nd.allgather_rows(nxt[ra:rb], send, async_op=True))
+                keep.append(send)
+                nrm_u.append(nrm)
+            for wk in works:
+                wk.wait()
+            blocks_u.append(torch.cat(nrm_u, 0))
+            blocks_i.append(nrm_i)
             full = nxt
+            # every real node's row arrived; only padding rows stay NaN
+            assert not torch.isnan(full[pos_all]).any()
         got_u, got_i = torch.cat(blocks_u, 1), torch.cat(blocks_i, 1)
         assert torch.allclose(got_u, want[ub[rank]:ub[rank + 1]], atol=1e-6)
         assert torch.allclose(got_i, want[ib[rank]:ib[rank + 1]], atol=1e-6)
@@ -160,6 +184,13 @@ def test_layout_and_bounds_single_process():
     for q in range(2):                                            # chunks are contiguous and rank-major
         assert pos[ub[q]:ub[q + 1]].tolist() == list(range(lay.user_pos(q), lay.user_pos(q) + lay.n_users_of(q)))
         assert pos[ib[q]:ib[q + 1]].tolist() == list(range(lay.item_pos(q), lay.item_pos(q) + lay.n_items_of(q)))
+    # chunked layout: chunk-major, then rank-major; an empty chunk (repeated bound) holds nobody
+    cl = nd.ShardLayout(5, 5, [0, 4, 5], [5, 9, 10], [0, 1, 1, 4, 4, 5, 5])          # W = 2, C = 3
+    assert (cl.chunks, cl.mc, cl.mi, cl.P) == (3, 3, 4, 2 * (3 * 3 + 4))
+    assert cl.to_padded(torch.arange(5)).tolist() == [0, 12, 13, 14, 9]          # user 4 = chunk 1 of rank 1
+    assert cl.to_padded(torch.arange(5, 10)).tolist() == [18, 19, 20, 21, 22]
+    assert cl.chunk_region(1) == (6, 12) and cl.user_pos(1, 2) == 15 and cl.n_users_of(0, 1) == 0
+    assert nd.chunk_bounds(cnt, [0, 4, 5], 2)[::2] == [0, 4, 5]
     assert nd.even_bounds(0, 10, 4) == [0, 2, 5, 7, 10]
     r, c, v = nd.slab_coo(torch.tensor([0, 0, 2, 3, 3]), torch.arange(5), torch.ones(5), 2, 4)
     assert r.tolist() == [0, 1, 1] and c.tolist() == [2, 3, 4]
@@ -168,8 +199,10 @@ def test_layout_and_bounds_single_process():
 # ------------------------------------------------------------------------------------------------
 # GPU: the real sharded HIP path, two ranks on one device
 # ------------------------------------------------------------------------------------------------
-def _gpu_worker(rank, world, port, mode, ret, backend="gloo"):
+def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if cabi:
+        os.environ["NGCF_DIST_COLLECTIVES"] = "cabi"              # ngcf_allgather_rows on the process group's communicator
     if backend == "nccl":
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
@@ -185,7 +218,14 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo"):
         torch.manual_seed(7)
         model = pkg.NGCF(128, [128, 64], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 64, dev).to(dev).eval()
         want = model.propagate(0).detach().clone()
-        sh = nd.ShardedPropagation(model, coo["rows"], coo["cols"], coo["vals"], mode=mode)
+        if mode == "allgather":
+            # slabs cut from HOST interaction triplets (only this rank's part reaches the device), user slab in 3 chunks
+            iu, ii, iw = (t.cpu() for t in pkg.graphs.synthetic_interactions(U, I, 90000, seed=3, device=dev))
+            sh = nd.ShardedPropagation.from_interactions(model, iu, ii, iw, mode=mode, chunks=3, device=dev)
+            assert sh.chunks == 3 and len(sh.csr_u) == 3 and (sh._cabi is not None) == cabi
+            assert sum(c.nnz for c in sh.csr_u) + sh.csr_i.nnz <= coo["nnz"] // world + coo["nnz"] // 10
+        else:
+            sh = nd.ShardedPropagation.from_coo(model, coo["rows"], coo["cols"], coo["vals"], mode=mode)
         au, ai = sh.propagate()
         if mode == "bipartite":
             lo, hi = sh.ub[rank], sh.ub[rank + 1]
@@ -226,4 +266,14 @@ def test_sharded_propagation_one_rank_over_rccl(mode):
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_gpu_worker, args=(1, _free_port(), mode, ret, "nccl"), nprocs=1, join=True)
+        assert dict(ret) == {0: True}
+
+
+@pytest.mark.gpu
+def test_allgather_rows_c_entry_point_on_the_process_groups_communicator():
+    """ngcf_allgather_rows (include/ngcf_hip.h) driving ncclAllGather itself on the RCCL communicator of the process group,
+    on a stream of its own: the chunked all-gather scheme end to end with the one rank a one-GPU box allows."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gpu_worker, args=(1, _free_port(), "allgather", ret, "nccl", True), nprocs=1, join=True)
         assert dict(ret) == {0: True}

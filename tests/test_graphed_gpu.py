@@ -48,6 +48,20 @@ def test_graphed_forward_replays_the_eager_forward(embed, layers, dev):
             assert torch.equal(a, b)
         assert torch.equal(graphed_model.user_embedding.weight.detach(), eager.user_embedding.weight.detach())
         assert torch.equal(graphed_model.all_items_emb, eager.all_items_emb)
+    # eager calls on the SAME module in between (another year slice, a training step that builds the transposed CSR and
+    # grows the module's workspace) must not disturb what the captured graph writes through: it owns its buffers
+    other = _batch(g, B, U, I, dev)
+    other["year"] = torch.full((B,), 19, device=dev)
+    for m in (eager, graphed_model):
+        m(node_flag=False, **other)
+        m.train()
+        u, p, n = m(node_flag=False, **other)
+        pkg.BPR(0.025, B)(u, p, n).backward()
+        m.zero_grad()
+        m.eval()
+    batch = _batch(g, B, U, I, dev)
+    want, got = eager(node_flag=False, **batch), fwd(node_flag=False, **batch)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
     bad = _batch(g, B, U, I, dev)
     bad["pos_item"][5] = I                                                        # out of range -> IndexError, like eager
     with pytest.raises(IndexError):

@@ -62,9 +62,12 @@ def test_module_device_node_dropout_forward_and_gradients():
     model.node_dropout_mode = "device"
     batch = {k: v.to(dev) for k, v in b.items()}
     torch.manual_seed(77)
-    seeds = [int(x) for x in torch.randint(0, 2 ** 62, (3,), dtype=torch.int64)]     # what the module will draw
-    torch.manual_seed(77)
+    # what the module will draw: its private generator follows torch.manual_seed without consuming the default stream
+    seeds = [int(x) for x in torch.randint(0, 2 ** 62, (3,), dtype=torch.int64,
+                                           generator=torch.Generator().manual_seed(77 ^ 0x5DEECE66D))]
+    state = torch.get_rng_state()
     u, p, n = model(node_flag=True, **batch)
+    assert torch.equal(torch.get_rng_state(), state)                 # device mode leaves the default CPU generator alone
     loss = pkg.BPR(0.025, len(b["u_id"]))(u, p, n)
     loss.backward()
     # oracle on the explicitly thinned matrices

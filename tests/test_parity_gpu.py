@@ -134,6 +134,86 @@ def test_module_node_dropout_reference_mode_matches_golden_edge_sets(dev):
     np.testing.assert_allclose(got, want.numpy(), atol=ATOL, rtol=RTOL)
 
 
+def test_module_train_mode_forward_matches_golden_masks(dev):
+    """Training-mode forward (NGCF.py:123-142): node dropout AND message dropout, both in "reference" mode, drawn from
+    torch's default CPU generator in the reference's order (per layer: node mask, then message noise).  With the fixture's
+    generator state the zero pattern of every layer block is bit-identical to the reference's and the values agree with
+    the reference's train-mode all_E at the forward tolerance.  Two forwards in a row consume the generator exactly as
+    two reference forwards do."""
+    pkg = _pkg()
+    g = load_golden("fwd_train_dropout")
+    sd, b = sd_of(g), batch_of(g)
+    model = pkg.NGCF(**ctor_args(g, lap_list_of(g, dev), dev)).to(dev)
+    model.load_state_dict(sd)
+    model.train()
+    assert model.mess_dropout_mode == "reference" and model.node_dropout_mode == "reference"
+    batch = {k: v.to(dev) for k, v in b.items()}
+    # the oracle on this machine's torch, same generator state, two forwards in a row
+    user_w = torch.from_numpy(g["out_user_weight_after"])
+    w1, b1, w2, b2 = layer_params(sd, 3)
+    L = lap_list_of(g)[int(g["year_idx"])]
+    mess, pn = [float(x) for x in g["mess"]], float(g["meta"][5])
+    torch.set_rng_state(torch.from_numpy(g["rng_state"]))
+    want = [orc.propagate_torch(L, user_w, sd["item_embedding.weight"], w1, b1, w2, b2, mess_dropout=mess, training=True,
+                                node_dropout=pn, node_flag=True, return_carry=True) for _ in range(2)]
+    state_after = torch.get_rng_state()
+    torch.set_rng_state(torch.from_numpy(g["rng_state"]))
+    with torch.no_grad():
+        got = []
+        for _ in range(2):
+            model(node_flag=True, **batch)
+            got.append(torch.cat((model.all_users_emb, model.all_items_emb), 0).detach().cpu().numpy())
+    assert torch.equal(torch.get_rng_state(), state_after)            # same number of draws as the reference path
+    d0 = int(g["meta"][2])
+    for (w_all, w_carries), mine in zip(want, got):
+        off = d0
+        for c in w_carries:
+            blk = mine[:, off:off + c.shape[1]]
+            assert np.array_equal(blk == 0, c.numpy() == 0)            # bit-identical message + node masks
+            off += c.shape[1]
+        np.testing.assert_allclose(mine, w_all.numpy(), atol=ATOL, rtol=RTOL)
+    # and against the reference's own outputs stored in the fixture, wherever this host's torch draws the same Bernoulli
+    # stream as the machine that generated it (the CPU bernoulli kernel is chosen by build and CPU vendor)
+    same_stream = all(np.array_equal(want[0][1][k].numpy() == 0, g[f"carry_{k}"] == 0) for k in range(3))
+    if same_stream:
+        np.testing.assert_allclose(got[0], g["out_all_E"], atol=ATOL, rtol=RTOL)
+        off = d0
+        for k in range(3):
+            assert np.array_equal(got[0][:, off:off + g[f"carry_{k}"].shape[1]] == 0, g[f"carry_{k}"] == 0)
+            off += g[f"carry_{k}"].shape[1]
+
+
+def test_reference_mode_message_dropout_gradients(dev):
+    """Backward through the host-drawn noise tensor: every parameter gradient vs torch autograd through the oracle."""
+    pkg = _pkg()
+    g = load_golden("fwd_train_dropout")
+    sd, b = sd_of(g), batch_of(g)
+    model = pkg.NGCF(**ctor_args(g, lap_list_of(g, dev), dev)).to(dev)
+    model.load_state_dict(sd)
+    model.train()
+    batch = {k: v.to(dev) for k, v in b.items()}
+    torch.set_rng_state(torch.from_numpy(g["rng_state"]))
+    u, p, n = model(node_flag=True, **batch)
+    loss = pkg.BPR(0.025, len(b["u_id"]))(u, p, n)
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(("w1_list", "w2_list", "item_emb"))}
+    uw = torch.from_numpy(g["out_user_weight_after"]).clone().requires_grad_(True)
+    w1, b1, w2, b2 = ([leaves[f"{n_}.{k}.{t}"] for k in range(3)]
+                      for n_, t in (("w1_list", "weight"), ("w1_list", "bias"), ("w2_list", "weight"), ("w2_list", "bias")))
+    torch.set_rng_state(torch.from_numpy(g["rng_state"]))
+    all_E = orc.propagate_torch(lap_list_of(g)[int(g["year_idx"])], uw, leaves["item_embedding.weight"], w1, b1, w2, b2,
+                                mess_dropout=[float(x) for x in g["mess"]], training=True, node_dropout=float(g["meta"][5]),
+                                node_flag=True)
+    ou, op, on = orc.gather_torch(all_E, int(g["meta"][0]), b["u_id"], b["pos_item"], b["neg_item"])
+    want_loss = orc.bpr_torch(ou, op, on, 0.025, len(b["u_id"]))
+    want_loss.backward()
+    assert abs(float(loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
+    named = dict(model.named_parameters())
+    for k, leaf in list(leaves.items()) + [("user_embedding.weight", uw)]:
+        scale = float(leaf.grad.abs().max())
+        np.testing.assert_allclose(named[k].grad.cpu().numpy(), leaf.grad.numpy(), atol=2e-3 * scale + 1e-9, rtol=2e-3, err_msg=k)
+
+
 # --------------------------------------------------------------------------------------------
 # SpMM kernel vs the plain-C oracle
 # --------------------------------------------------------------------------------------------

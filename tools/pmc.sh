@@ -5,6 +5,7 @@
 set -e
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export NGCF_NO_BUILD=1   # the profiler initialises the GPU in every process of the tree: never spawn a compiler under it
 mkdir -p "$out"
 for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   tag=$(echo $ctr | tr ' ' '_')

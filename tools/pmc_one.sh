@@ -2,6 +2,7 @@
 # usage: tools/pmc_one.sh <outdir> "<counters>" <python script + args...>   (GPU box)
 out=$1; ctrs=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export NGCF_NO_BUILD=1   # the profiler initialises the GPU in every process of the tree: never spawn a compiler under it
 timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out" -- python "$@" > "$out.log" 2>&1
 python - "$out" <<'PY'
 import csv,glob,collections,sys
