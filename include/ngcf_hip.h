@@ -158,6 +158,10 @@ int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *E_self, int
  * NGCF.py:120-121 + 147). */
 int ngcf_copy_rows_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int d,
                        void *stream);
+/* The same with two destinations (the source rows are read once): E0 goes to its block of all_E and, when the rows of
+ * all_E are not 16-byte aligned (embed_size 65 / 130 / 515, NGCF.py:39-43), to the aligned copy the first layer gathers from. */
+int ngcf_copy_rows2_f32(const float *src, int64_t lds, float *dst, int64_t ldd, float *dst2, int64_t ldd2,
+                        int64_t n_rows, int d, void *stream);
 
 /* ---- feature injection (NGCF.py:103-115) ---------------------------------------------- */
 /*

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "ngcf_layer_dense_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
                                        _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_copy_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
+    "ngcf_copy_rows2_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_feature_inject_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_i64), C.c_int, _vp, _i64, C.c_double, _vp, _vp, _vp]),
     "ngcf_gather_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),

@@ -18,20 +18,27 @@ from . import engine as _eng
 from .engine import _ptr, _row_major_ld, _stream
 
 
-def _first_layer_input(owner, user_w, item_w, all_E, U, d0):
-    """E0 as the first layer reads it.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130,
-    515), so D is usually not a multiple of 4 and the rows of all_E are not 16-byte aligned; the first layer then
-    reads a copy whose rows are padded to a multiple of 4 floats, which lets the SpMM run its wide panel on the
-    float4 / L2-swept kernels (csrc/spmm.hip, spmm_dispatch) instead of scalar loads."""
+def _write_e0(owner, user_w, item_w, all_E, U, d0):
+    """E0 into its column block of all_E (the `cat` of NGCF.py:120 and of NGCF.py:147); returns E0 as the first layer
+    reads it.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130, 515), so D is usually not a
+    multiple of 4 and the rows of all_E are not 16-byte aligned; the first layer then reads a second copy whose rows are
+    padded to a multiple of 4 floats (written in the same pass over the tables), which lets the SpMM run its wide panel
+    on the float4 / L2-swept kernels (csrc/spmm.hip, spmm_dispatch) instead of scalar loads."""
+    uw, iw = user_w.detach(), item_w.detach()
     if all_E.shape[1] % 4 == 0 and d0 % 4 == 0:
+        _eng.copy_rows(uw, all_E[:U, :d0])
+        _eng.copy_rows(iw, all_E[U:, :d0])
         return all_E[:, :d0]
-    N, d0p = all_E.shape[0], (d0 + 3) // 4 * 4
+    # leading dimension a multiple of 32 floats: every 64-float slice of a row then starts on a 128-byte line, as in the
+    # aligned case (with rows padded to a multiple of 4 only, a slice straddles three lines instead of two and the L2-swept
+    # SpMM of the first layer ran 2.5 instead of 1.55 ms per half on C3 at 130)
+    N, d0p = all_E.shape[0], (d0 + 31) // 32 * 32
     pad = getattr(owner, "_e0_pad", None)
     if pad is None or pad.device != all_E.device or tuple(pad.shape) != (N, d0p):
         pad = torch.zeros((N, d0p), dtype=torch.float32, device=all_E.device)
         owner._e0_pad = pad
-    _eng.copy_rows(user_w.detach(), pad[:U, :d0])
-    _eng.copy_rows(item_w.detach(), pad[U:, :d0])
+    _eng.copy_rows(uw, all_E[:U, :d0], pad[:U, :d0])
+    _eng.copy_rows(iw, all_E[U:, :d0], pad[U:, :d0])
     return pad[:, :d0]
 
 
@@ -51,9 +58,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
     widths = [d0] + [int(w.shape[0]) for w in w1]
     D = sum(widths)
     all_E = torch.empty((N, D), dtype=torch.float32, device=dev)
-    _eng.copy_rows(user_w.detach(), all_E[:U, :d0])
-    _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
-    prev = _first_layer_input(owner, user_w, item_w, all_E, U, d0)
+    prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
     off = d0
     for k in range(n_layer):
         d_out = widths[k + 1]
@@ -132,7 +137,7 @@ def _bwd_weight(dM, LE, E, ws):
 def _bwd_combine(dSP, LE, E):
     lib = _lib.load()
     n_rows, d = LE.shape
-    d4 = (d + 3) // 4 * 4      # 16-byte aligned rows: L^T . dLE then runs on the float4 / swept kernels at any width
+    d4 = (d + 31) // 32 * 32   # 128-byte aligned rows: L^T . dLE then runs on the float4 / swept kernels at any width
     dLE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
     dE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
     with torch.cuda.device(LE.device):
@@ -160,9 +165,7 @@ class Propagate(torch.autograd.Function):
         N, d0 = U + I, int(user_w.shape[1])
         widths = [d0] + [int(w.shape[0]) for w in w1]
         all_E = torch.empty((N, sum(widths)), dtype=torch.float32, device=dev)
-        _eng.copy_rows(user_w.detach(), all_E[:U, :d0])
-        _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
-        prev = _first_layer_input(owner, user_w, item_w, all_E, U, d0)
+        prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
         off = d0
         ins, les, carries = [], [], []
         for k in range(n_layer):

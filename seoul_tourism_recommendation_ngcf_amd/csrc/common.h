@@ -154,6 +154,7 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
 // ---------------------------------------------------------------------------------------------
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<2> { using type = float2; };
 template <> struct VecT<1> { using type = float; };
 
 __device__ inline float4 vfma(float s, float4 x, float4 a)

@@ -80,15 +80,23 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
 
     auto load_chunk = [&](int chunk) {       // global -> registers
         const int c0 = chunk * NGCF_DC + sq * 4;
-        if constexpr (FAST) {   // every chunk is a full, 16-byte aligned float4 per lane
-            // branch-free: rows past the end re-read the last row (never stored), so the loads stay in flight
-            // under the MFMAs of the current chunk instead of being waited for inside a conditional
+        if constexpr (FAST) {   // 16-byte aligned rows padded to a multiple of 4 floats: one float4 per lane and operand
+            // branch-free: rows past the end re-read the last row (never stored) and columns past d_in re-read the last
+            // float4 of the row and are zeroed (the padding columns of LE hold no defined values), so the loads stay in
+            // flight under the MFMAs of the current chunk instead of being waited for inside a conditional
+            const int d4 = (d_in + 3) & ~3;
+            const int cc = c0 < d4 ? c0 : d4 - 4;
+            const bool k0 = c0 < d_in, k1 = c0 + 1 < d_in, k2 = c0 + 2 < d_in, k3 = c0 + 3 < d_in;
 #pragma unroll
             for (int rr = 0; rr < RR; ++rr) {
                 int64_t grow = row0 + (sr + rr * 64) % BM;
                 grow = grow < n_rows ? grow : n_rows - 1;
-                xle[rr] = *reinterpret_cast<const f32x4 *>(LE + grow * ldLE + c0);
-                xe[rr] = *reinterpret_cast<const f32x4 *>(Es + grow * ldE + c0);
+                f32x4 a = *reinterpret_cast<const f32x4 *>(LE + grow * ldLE + cc);
+                f32x4 b = *reinterpret_cast<const f32x4 *>(Es + grow * ldE + cc);
+                a.x = k0 ? a.x : 0.f; a.y = k1 ? a.y : 0.f; a.z = k2 ? a.z : 0.f; a.w = k3 ? a.w : 0.f;
+                b.x = k0 ? b.x : 0.f; b.y = k1 ? b.y : 0.f; b.z = k2 ? b.z : 0.f; b.w = k3 ? b.w : 0.f;
+                xle[rr] = a;
+                xe[rr] = b;
             }
             const f32x4 *srcw = reinterpret_cast<const f32x4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
 #pragma unroll
@@ -278,7 +286,7 @@ static int launch_dense(bool al, int64_t n_rows, const float *LE, int64_t ldLE, 
 {
     const int64_t blocks = (n_rows + 32 * RW - 1) / (32 * RW);
     if (blocks == 0) return NGCF_OK;
-    if (al && d_in % NGCF_DC == 0)
+    if (al && ldLE >= align_up(d_in, 4) && ldE >= align_up(d_in, 4) && d_in >= 4)   // padded, aligned rows (any d_in)
         layer_dense_kernel<RW, CW, NT, true, true><<<dim3((unsigned)blocks), 256, 0, stream>>>(
             LE, ldLE, Es, ldE, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, seed, drop_mask, ldm, carry, ldc, norm, ldn);
     else if (al)
@@ -334,7 +342,7 @@ extern "C" int64_t ngcf_layer_workspace_bytes(const ngcf_csr_t *c, int d_in, int
     const int64_t a = ngcf_spmm_workspace_bytes(c, d_in);
     const int64_t b = ngcf_dense_workspace_bytes(d_in, d_out);
     if (a < 0 || b < 0) return -1;
-    const int64_t le = align_up(c->n_rows * align_up(d_in, 4) * (int64_t)sizeof(float), 256);
+    const int64_t le = align_up(c->n_rows * align_up(d_in, 32) * (int64_t)sizeof(float), 256);   // LE rows start on 128-byte lines
     return a + b + le + 256;
 }
 
@@ -350,7 +358,7 @@ extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_
     if (!workspace || workspace_bytes < need)
         return fail(NGCF_ERR_WORKSPACE, "layer_fused: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
     char *ws = reinterpret_cast<char *>(align_up((int64_t)(uintptr_t)workspace, 256));
-    const int64_t ldLE = align_up(d_in, 4);
+    const int64_t ldLE = align_up(d_in, 32);
     float *LE = reinterpret_cast<float *>(ws);
     ws += align_up(c->n_rows * ldLE * (int64_t)sizeof(float), 256);
     const int64_t spmm_ws = ngcf_spmm_workspace_bytes(c, d_in);

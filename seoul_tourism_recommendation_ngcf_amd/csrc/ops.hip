@@ -4,9 +4,11 @@
 // ---------------------------------------------------------------------------------------------
 // strided row copy (E0 -> its block of all_E), NGCF.py:120-121,147
 // ---------------------------------------------------------------------------------------------
+// dst2 (optional): a second copy of the same rows with another leading dimension (the 16-byte aligned E0 the first layer
+// gathers from when the rows of all_E are not: embed_size 65/130/515) - the source is read once
 template <int VEC>
 __global__ void copy_rows_kernel(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
-                                 int64_t n_rows, int d)
+                                 float *__restrict__ dst2, int64_t ldd2, int64_t n_rows, int d)
 {
     using V = typename VecT<VEC>::type;
     const int per_row = d / VEC;
@@ -16,23 +18,43 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, int64_t lds, flo
     for (; i < total; i += stride) {
         const int64_t r = i / per_row;
         const int q = (int)(i % per_row) * VEC;
-        *reinterpret_cast<V *>(dst + r * ldd + q) = *reinterpret_cast<const V *>(src + r * lds + q);
+        const V v = *reinterpret_cast<const V *>(src + r * lds + q);
+        *reinterpret_cast<V *>(dst + r * ldd + q) = v;
+        if (dst2) *reinterpret_cast<V *>(dst2 + r * ldd2 + q) = v;
     }
+}
+
+static int copy_rows_impl(const float *src, int64_t lds, float *dst, int64_t ldd, float *dst2, int64_t ldd2, int64_t n_rows, int d,
+                          hipStream_t stream)
+{
+    if (!src || !dst || d <= 0 || n_rows < 0 || lds < d || ldd < d || (dst2 && ldd2 < d)) return fail(NGCF_ERR_ARG, "copy_rows: bad argument");
+    if (n_rows == 0) return NGCF_OK;
+    auto al = [&](int v) {   // every row of every operand is a whole number of v-float vectors at a v*4-byte aligned address
+        const uintptr_t m = (uintptr_t)v * 4 - 1;
+        return d % v == 0 && lds % v == 0 && ldd % v == 0 && !((uintptr_t)src & m) && !((uintptr_t)dst & m) &&
+               (!dst2 || (ldd2 % v == 0 && !((uintptr_t)dst2 & m)));
+    };
+    if (al(4))
+        copy_rows_kernel<4><<<grid_for(n_rows * (d / 4), 256), 256, 0, stream>>>(src, lds, dst, ldd, dst2, ldd2, n_rows, d);
+    else if (al(2))
+        copy_rows_kernel<2><<<grid_for(n_rows * (d / 2), 256), 256, 0, stream>>>(src, lds, dst, ldd, dst2, ldd2, n_rows, d);
+    else
+        copy_rows_kernel<1><<<grid_for(n_rows * d, 256), 256, 0, stream>>>(src, lds, dst, ldd, dst2, ldd2, n_rows, d);
+    LAUNCH_CHECK();
+    return NGCF_OK;
 }
 
 extern "C" int ngcf_copy_rows_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int d,
                                   void *stream_)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!src || !dst || d <= 0 || n_rows < 0 || lds < d || ldd < d) return fail(NGCF_ERR_ARG, "copy_rows: bad argument");
-    if (n_rows == 0) return NGCF_OK;
-    const bool vec = d % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst);
-    if (vec)
-        copy_rows_kernel<4><<<grid_for(n_rows * (d / 4), 256), 256, 0, stream>>>(src, lds, dst, ldd, n_rows, d);
-    else
-        copy_rows_kernel<1><<<grid_for(n_rows * d, 256), 256, 0, stream>>>(src, lds, dst, ldd, n_rows, d);
-    LAUNCH_CHECK();
-    return NGCF_OK;
+    return copy_rows_impl(src, lds, dst, ldd, nullptr, 0, n_rows, d, (hipStream_t)stream_);
+}
+
+extern "C" int ngcf_copy_rows2_f32(const float *src, int64_t lds, float *dst, int64_t ldd, float *dst2, int64_t ldd2,
+                                   int64_t n_rows, int d, void *stream_)
+{
+    if (!dst2) return fail(NGCF_ERR_ARG, "copy_rows2: null second destination");
+    return copy_rows_impl(src, lds, dst, ldd, dst2, ldd2, n_rows, d, (hipStream_t)stream_);
 }
 
 // ---------------------------------------------------------------------------------------------

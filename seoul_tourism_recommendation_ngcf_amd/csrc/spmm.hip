@@ -93,6 +93,54 @@ __global__ void tail_unpack_kernel(const float4 *__restrict__ T, int64_t n, int 
     }
 }
 
+// The tail product itself: [n_rows, 4] = L . T[n_cols, 4].  16 lanes per row (or per <= seg_len-entry segment of a cut row),
+// four of them per wave, four independent (col, val, gather) triples in flight per lane: a 50-entry user row is one pass of
+// its group.  One wave per row (spmm_kernel<4,1,1,1>) is latency-bound at ~0.5 us per row: 1.0 ms per product on C3, this
+// form 0.3 ms.
+__global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                        const float *__restrict__ vals, int64_t n_rows,
+                                                        const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
+                                                        int64_t n_seg, int64_t seg_blocks, int seg_len, const float4 *__restrict__ T,
+                                                        float4 *__restrict__ out, float4 *__restrict__ partial)
+{
+    const int unit = threadIdx.x >> 4, l = threadIdx.x & 15;
+    int64_t begin = 0, end = 0;
+    float4 *dst = nullptr;
+    if ((int64_t)blockIdx.x < seg_blocks) {
+        const int64_t s = (int64_t)blockIdx.x * 16 + unit;
+        if (s < n_seg) {
+            begin = seg_begin[s];
+            const int64_t row_end = rowptr[seg_row[s] + 1];
+            end = begin + seg_len < row_end ? begin + seg_len : row_end;
+            dst = partial + s;
+        }
+    } else {
+        const int64_t row = ((int64_t)blockIdx.x - seg_blocks) * 16 + unit;
+        if (row < n_rows) {
+            begin = rowptr[row];
+            end = rowptr[row + 1];
+            dst = out + row;
+            if (end - begin > seg_len) dst = nullptr, end = begin;   // cut row: produced from its segments
+        }
+    }
+    float4 a0 = vzero4(), a1 = vzero4(), a2 = vzero4(), a3 = vzero4();
+    for (int64_t e = begin + l; e < end; e += 64) {
+        const int64_t e1 = e + 16, e2 = e + 32, e3 = e + 48;
+        const bool k1 = e1 < end, k2 = e2 < end, k3 = e3 < end;
+        const int c0 = colidx[e], c1 = k1 ? colidx[e1] : 0, c2 = k2 ? colidx[e2] : 0, c3 = k3 ? colidx[e3] : 0;
+        const float v0 = vals[e], v1 = k1 ? vals[e1] : 0.f, v2 = k2 ? vals[e2] : 0.f, v3 = k3 ? vals[e3] : 0.f;
+        const float4 t0 = T[c0], t1 = T[c1], t2 = T[c2], t3 = T[c3];
+        a0 = vfma(v0, t0, a0);
+        a1 = vfma(v1, t1, a1);
+        a2 = vfma(v2, t2, a2);
+        a3 = vfma(v3, t3, a3);
+    }
+    float4 acc = vadd(vadd(a0, a1), vadd(a2, a3));
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) acc = vadd(acc, vshfl_xor(acc, m));
+    if (l == 0 && dst) *dst = acc;
+}
+
 static int64_t tail_table_bytes(const ngcf_csr *c)
 {
     return align_up(c->n_cols * (int64_t)sizeof(float4), 256) + align_up(c->n_rows * (int64_t)sizeof(float4), 256) + 512;
@@ -257,9 +305,21 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
                                                          ~(uintptr_t)255);
                 tail_pack_kernel<<<grid_for(c->n_cols, 256), 256, 0, stream>>>(E + main, ldE, c->n_cols, tail, Tin);
                 LAUNCH_CHECK();
-                const int rc2 = spmm_dispatch(c, reinterpret_cast<const float *>(Tin), 4, 4, reinterpret_cast<float *>(Tout), 4, workspace,
-                                              reinterpret_cast<char *>(Tin) - reinterpret_cast<char *>(workspace), stream, dr);
-                if (rc2 != NGCF_OK) return rc2;
+                // cut rows (the CSR's own segment plan): partial float4 per segment at the start of the workspace, then the fix-up
+                float4 *tpart = reinterpret_cast<float4 *>(align_up((int64_t)(uintptr_t)workspace, 256));
+                const int64_t seg_blocks = (c->n_seg + 15) / 16, row_blocks = (c->n_rows + 15) / 16;
+                if (seg_blocks + row_blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+                prof_mark(stream, 0);
+                spmm_tail_kernel<<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(
+                    c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, Tin, Tout, tpart);
+                LAUNCH_CHECK();
+                if (c->n_heavy > 0) {
+                    spmm_fixup_kernel<4><<<dim3((unsigned)((c->n_heavy + 3) / 4)), 256, 0, stream>>>(
+                        c->heavy_row, c->heavy_seg_ptr, c->n_heavy, reinterpret_cast<const float *>(tpart), 4, 4,
+                        reinterpret_cast<float *>(Tout), 4);
+                    LAUNCH_CHECK();
+                }
+                prof_mark(stream, 1);
                 tail_unpack_kernel<<<grid_for(c->n_rows, 256), 256, 0, stream>>>(Tout, c->n_rows, tail, out + main, ldo);
                 LAUNCH_CHECK();
                 return NGCF_OK;
@@ -284,8 +344,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     if (rc != NGCF_OK) return rc;
     if (vec) {
         const int nq = d / 4;
-        if (nq == 1) rc = launch_spmm<4, 1, 1, 1>(a);          // 16-byte rows (compact tail table): 64 entries per instruction
-        else if (nq <= 8) rc = launch_spmm<4, 8, 1, 4>(a);
+        if (nq <= 8) rc = launch_spmm<4, 8, 1, 4>(a);
         else if (nq <= 16) rc = launch_spmm<4, 16, 1, 8>(a);
         else if (nq <= 32) rc = launch_spmm<4, 32, 1, 8>(a);
         else if (nq <= 64) rc = launch_spmm<4, 64, 1, 8>(a);

@@ -42,12 +42,13 @@ int env_int(const char *name, int dflt)
 }
 
 template <typename F>
-void parallel_for(int64_t n, F &&fn)
+void parallel_for(int64_t n, F &&fn, int64_t min_parallel = 64)
 {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
-    if (n < 64 || nt == 1) {
+    if ((int64_t)nt > n) nt = (unsigned)std::max<int64_t>(n, 1);
+    if (n < min_parallel || nt == 1) {
         fn(0, n);
         return;
     }
@@ -111,11 +112,11 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     const int64_t e0 = rp[0], nnz = rp[(size_t)n] - e0;
     if (nnz <= 0) return NGCF_OK;
     if (!force && nnz < ((int64_t)1 << 22)) return NGCF_OK;          // small products are launch-bound, not L2-bound
-    // workgroup shape: 16 waves x 36 rows, or 8 x 72 when the rows need three or more passes (short wave tasks).  On
-    // the 7-pass user rows of C3 both run in 2.0 ms but 8 waves fetch 30 % less (PMC: 5.8 vs 8.4 GB); on the one-pass
-    // item rows 8 waves are 20 % slower.  NGCF_SWEPT_WAVES overrides (experiments, tests).
+    // workgroup shape: 16 waves x 36 rows.  (Round 1 ran the parts that need three or more row passes as 8 x 72: fewer,
+    // longer wave tasks fetched 30 % less.  With the lag-driven wave priorities of the kernel 16 waves are faster there
+    // too - C3 user rows 1.60 vs 1.93 ms, profiles/r02_swept_lab.txt.)  NGCF_SWEPT_WAVES overrides (experiments, tests).
     const int64_t cap = (int64_t)kSweptWGs * kLdsRows;               // output rows resident in LDS at a time
-    int waves = (n + cap - 1) / cap >= 3 ? 8 : 16;
+    int waves = 16;
     if (env_int("NGCF_SWEPT_WAVES", 0) == 8 || env_int("NGCF_SWEPT_WAVES", 0) == 16) waves = env_int("NGCF_SWEPT_WAVES", 0);
     const int RW = kLdsRows / waves;
     const int64_t n_wave_slots = (int64_t)kSweptWGs * waves;
@@ -161,24 +162,106 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
         if (n_rowpass > (int64_t)1 << 20) return fail(NGCF_ERR_ARG, "swept plan: cannot place %zu pieces", pieces.size());
     }
     if (n_tasks * RW >= (int64_t)1 << 31 || n_partial >= ((int64_t)1 << 31) - 2) return fail(NGCF_ERR_ARG, "swept plan: matrix too large");
-    // level by level, heaviest piece -> lightest task (every task gets at most one piece per level)
+    // Dealing.  Level by level, heaviest piece -> lightest task (every task gets at most one piece per level): all tasks end
+    // within +-2 % of the same entry count.  That alone leaves WHERE in the table a task's entries lie to chance, and the
+    // sweep pays for it: a wave whose rows happen to hold few entries in the first half of the table runs ahead of the
+    // others by (missing entries) / (entries per column) - on the C3 item rows sigma = 1.1 MiB of table slice, 4 096 waves
+    // spread over ~10 MiB against a 4 MiB L2 (measured with tools/swept_trace_lab.py, profiles/r02_swept_trace.txt; a table
+    // row is then fetched again for the late waves).  So inside buckets of kDealBucket neighbouring (task, piece) pairs of a
+    // level - equal loads to within a fraction of a percent - the pairing is chosen to cancel the low-order cosine moments
+    // of every task's entry positions (position = share of all entries left of the column, so that a uniform sweep is the
+    // target whatever the column popularity): m_k = sum over entries of cos(k pi x), k = 1..kDealK, are the sine-series
+    // coefficients of the task's cumulative-count deviation; the greedy gives each piece to the task of its bucket whose
+    // moments it cancels best.  Simulated on the C3 item rows: spread (p5..p95) 2.9 -> 0.9 MiB, worst wave 4.6 -> 2.0 MiB.
+    constexpr int kDealK = 8, kDealBucket = 256;
+    const bool balance_moments = !getenv("NGCF_SWEPT_NO_MOMENTS");
+    std::vector<float> mom;                                          // [piece][kDealK]
+    if (balance_moments) {
+        const int64_t span = (int64_t)col_hi - col_lo + 1;
+        std::vector<int64_t> ccnt((size_t)span + 1, 0);
+        for (int64_t x = 0; x < nnz; ++x) ccnt[(size_t)(col[(size_t)x] - col_lo) + 1]++;
+        for (int64_t c = 0; c < span; ++c) ccnt[(size_t)c + 1] += ccnt[(size_t)c];
+        std::vector<float> ctab((size_t)span * kDealK);
+        parallel_for(span, [&](int64_t lo, int64_t hi) {
+            for (int64_t c = lo; c < hi; ++c) {
+                const double xpos = (0.5 * (double)(ccnt[(size_t)c] + ccnt[(size_t)c + 1])) / (double)nnz;
+                for (int k = 0; k < kDealK; ++k) ctab[(size_t)c * kDealK + k] = (float)cos((k + 1) * 3.14159265358979323846 * xpos);
+            }
+        });
+        mom.assign(pieces.size() * kDealK, 0.f);
+        parallel_for((int64_t)pieces.size(), [&](int64_t lo, int64_t hi) {
+            for (int64_t pi = lo; pi < hi; ++pi) {
+                const Piece &pc = pieces[(size_t)pi];
+                float acc[kDealK] = {0};
+                for (int64_t x = pc.begin + pc.off; x < pc.end; x += pc.step) {
+                    const float *t = &ctab[(size_t)(col[(size_t)x] - col_lo) * kDealK];
+                    for (int k = 0; k < kDealK; ++k) acc[k] += t[k];
+                }
+                for (int k = 0; k < kDealK; ++k) mom[(size_t)pi * kDealK + k] = acc[k];
+            }
+        });
+    }
     std::vector<int64_t> order(pieces.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return pieces[(size_t)a].count > pieces[(size_t)b].count; });
     std::vector<int64_t> load((size_t)n_tasks, 0), by_load((size_t)n_tasks);
+    std::vector<float> tmom(balance_moments ? (size_t)n_tasks * kDealK : 0, 0.f);   // moments of every task so far
     std::vector<int64_t> task_piece((size_t)(n_tasks * RW), -1);    // [task][local row] -> piece
     for (int64_t lvl = 0; lvl * n_tasks < (int64_t)pieces.size(); ++lvl) {
         std::iota(by_load.begin(), by_load.end(), 0);
         std::stable_sort(by_load.begin(), by_load.end(), [&](int64_t a, int64_t b) { return load[(size_t)a] < load[(size_t)b]; });
         const int64_t lo = lvl * n_tasks, hi = std::min<int64_t>((int64_t)pieces.size(), lo + n_tasks);
-        for (int64_t i = lo; i < hi; ++i) {
-            const int64_t t = by_load[(size_t)(i - lo)];
-            task_piece[(size_t)(t * RW + lvl)] = order[(size_t)i];
-            load[(size_t)t] += pieces[(size_t)order[(size_t)i]].count;
+        if (!balance_moments) {
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t t = by_load[(size_t)(i - lo)];
+                task_piece[(size_t)(t * RW + lvl)] = order[(size_t)i];
+                load[(size_t)t] += pieces[(size_t)order[(size_t)i]].count;
+            }
+            continue;
         }
+        const int64_t n_buckets = (hi - lo + kDealBucket - 1) / kDealBucket;
+        parallel_for(n_buckets, [&](int64_t b_lo, int64_t b_hi) {
+            std::vector<int64_t> ps, ts;
+            for (int64_t b = b_lo; b < b_hi; ++b) {
+                const int64_t i0 = lo + b * kDealBucket, i1 = std::min(hi, i0 + kDealBucket);
+                ps.assign(order.begin() + i0, order.begin() + i1);                      // pieces of the bucket ...
+                ts.assign(by_load.begin() + (i0 - lo), by_load.begin() + (i1 - lo));   // ... and its tasks
+                // pieces with the largest moments choose first
+                std::stable_sort(ps.begin(), ps.end(), [&](int64_t a, int64_t c) {
+                    float na = 0.f, nc = 0.f;
+                    for (int k = 0; k < kDealK; ++k) {
+                        na += fabsf(mom[(size_t)a * kDealK + k]);
+                        nc += fabsf(mom[(size_t)c * kDealK + k]);
+                    }
+                    return na > nc;
+                });
+                for (const int64_t pi : ps) {
+                    const float *pm = &mom[(size_t)pi * kDealK];
+                    size_t best = 0;
+                    float best_cost = 3.4e38f;
+                    for (size_t j = 0; j < ts.size(); ++j) {
+                        const float *tm = &tmom[(size_t)ts[j] * kDealK];
+                        float cost = 0.f;
+                        for (int k = 0; k < kDealK; ++k) cost += (tm[k] + pm[k]) * (tm[k] + pm[k]);
+                        if (cost < best_cost) {
+                            best_cost = cost;
+                            best = j;
+                        }
+                    }
+                    const int64_t t = ts[best];
+                    ts[best] = ts.back();
+                    ts.pop_back();
+                    task_piece[(size_t)(t * RW + lvl)] = pi;
+                    load[(size_t)t] += pieces[(size_t)pi].count;
+                    for (int k = 0; k < kDealK; ++k) tmom[(size_t)t * kDealK + k] += pm[k];
+                }
+            }
+        }, 2);
     }
     // 2) column windows and the slot layout of every (task, window) bucket
-    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", 8192);
+    // 8 MiB windows; 16 MiB when the table slice is 128 MiB or more (C3 item rows, lead 2: 1.58 vs 1.61 ms; on the 25 MiB
+    // table of the user rows 8 MiB: 1.53 vs 1.84 ms)
+    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", ((int64_t)col_hi - col_lo + 1) * kSW * 4 >= ((int64_t)128 << 20) ? 16384 : 8192);
     if (win_kb < 16) win_kb = 16;
     const int32_t win_cols = (int32_t)std::max<int64_t>(64, win_kb * 1024 / (kSW * 4));
     const int64_t n_win = ((int64_t)col_hi - col_lo) / win_cols + 1;
@@ -465,18 +548,22 @@ template <int U> __device__ inline float row_bcast(float x)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // RW accumulator rows per wave, NW waves per workgroup (NW*RW*256 B of LDS)
-template <int RW, int NW>
+// DBG: every kDbgEvery chunks a wave stores (s_memrealtime, column it is gathering) into `dbg` - the sweep-spread
+// trace of tools/swept_trace_lab.py (NGCF_SWEPT_TRACE=<file>); the product never runs this instantiation otherwise
+constexpr int kDbgEvery = 2, kDbgSamples = 512;
+template <int RW, int NW, bool DBG>
 __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__restrict__ tptr, const int32_t *__restrict__ e_pack,
                                                              const float *__restrict__ e_val, const int32_t *__restrict__ dst,
                                                              int n_rowpass, int n_win, int n_slices, const float *__restrict__ E,
                                                              int64_t ldE, float *__restrict__ out, int64_t ldo,
                                                              float *__restrict__ partial, int dp, unsigned *bar, int max_spin, int lead,
-                                                             int sync_k)
+                                                             int sync_k, unsigned prio_cols, int prio_graded, int nt_flags, unsigned long long *__restrict__ dbg)
 {
     __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];
     __shared__ int perm_lds;                    // highest sweep step this workgroup knows to be permitted
     __shared__ unsigned xcc_id;
+    __shared__ unsigned wg_front;               // furthest (sweep, column) any wave of this workgroup has reached
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, p = lane & 15;     // entry slot in the round, position in the slice
     const int held = p * kEPR + g;              // chunk entry this lane keeps: round u = lane u of every 16-lane row
@@ -485,6 +572,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
     if (threadIdx.x == 0) {
         xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID
         perm_lds = lead;                        // steps 0..lead wait for nobody
+        wg_front = 0;
     }
     __syncthreads();
     unsigned *ctr = bar + xcc_id * 32;
@@ -493,6 +581,9 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
     int perm = lead;                            // this wave's copy of perm_lds
     int step0 = 0;                              // sweep steps of the passes before this one
     const unsigned ld_bytes = (unsigned)ldE * 4u;
+    int dbg_n = 0, dbg_chunk = 0;
+    unsigned long long *dbg_w = DBG ? dbg + ((size_t)blockIdx.x * NW + wave) * (2 * kDbgSamples + 2) : nullptr;
+    if (DBG && lane == 0) dbg_w[0] = xcc_id;
     for (int rp = 0; rp < n_rowpass; ++rp) {
         const int64_t task = ((int64_t)rp * gridDim.x + blockIdx.x) * NW + wave;
         const int64_t *tp = tptr + task * n_win;
@@ -547,8 +638,13 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                 pk = idle_pk;
                 v = 0.f;
                 if (idx < end) {
-                    pk = e_pack[idx];
-                    v = e_val[idx];
+                    if (nt_flags & 1) {          // the entry lists are read once: streaming loads, they should not displace table rows in L2
+                        pk = __builtin_nontemporal_load(&e_pack[idx]);
+                        v = __builtin_nontemporal_load(&e_val[idx]);
+                    } else {
+                        pk = e_pack[idx];
+                        v = e_val[idx];
+                    }
                 }
             };
             if (end > beg) {
@@ -580,7 +676,35 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                 cross(beg, true);
                 offA = (unsigned)(pkA & kColMask) * ld_bytes;
                 NGCF_GATHER_LO(xa)
+                const unsigned sweep_tag = (unsigned)((rp * n_slices + slice) & 0xff) << kRowBits;
                 for (int64_t pos = beg; pos < end; pos += kCH) {
+                    if (prio_cols) {
+                        // Inside a workgroup the same few waves fall behind and stay behind (the instruction arbiter serves the
+                        // older wave of a SIMD first), up to 4.5 MiB of table on the C3 item rows while the workgroups themselves
+                        // stay within 0.3 MiB of each other (tools/swept_trace_lab.py): a wave that is more than prio_cols
+                        // columns behind the front of its workgroup raises its priority, the others run at 0.
+                        const unsigned mine = sweep_tag | (unsigned)(__builtin_amdgcn_readfirstlane(pkA) & kColMask);
+                        unsigned front = 0;
+                        if (lane == 0) front = atomicMax(&wg_front, mine);
+                        front = (unsigned)__builtin_amdgcn_readfirstlane((int)front);
+                        const unsigned lag = front > mine ? front - mine : 0u;
+                        if (prio_graded) {
+                            if (lag > 4 * prio_cols) __builtin_amdgcn_s_setprio(3);
+                            else if (lag > 2 * prio_cols) __builtin_amdgcn_s_setprio(2);
+                            else if (lag > prio_cols) __builtin_amdgcn_s_setprio(1);
+                            else __builtin_amdgcn_s_setprio(0);
+                        } else {
+                            if (lag > prio_cols) __builtin_amdgcn_s_setprio(3);
+                            else __builtin_amdgcn_s_setprio(0);
+                        }
+                    }
+                    if (DBG) {
+                        if (dbg_chunk++ % kDbgEvery == 0 && dbg_n < kDbgSamples && lane == 0) {
+                            dbg_w[2 + 2 * dbg_n] = __builtin_amdgcn_s_memrealtime();
+                            dbg_w[3 + 2 * dbg_n] = ((unsigned long long)(rp * n_slices + slice) << 32) | (unsigned)(pkA & kColMask);
+                            ++dbg_n;
+                        }
+                    }
                     load_entries(pos + kCH, pkB, vB);                // the next chunk's entries, two gathers ahead
                     const bool hi = pos + 8 * kEPR < end;
                     if (hi) {
@@ -613,12 +737,15 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                     const int drow = dst[task * RW + r];
                     if (drow != -1) {
                         float *o = drow >= 0 ? out + (int64_t)drow * ldo : partial + (int64_t)(-2 - drow) * dp;
-                        *reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4) = *reinterpret_cast<const f32x4 *>(wacc + r * kSW + p * 4);
+                        const f32x4 res = *reinterpret_cast<const f32x4 *>(wacc + r * kSW + p * 4);
+                        if (nt_flags & 2) __builtin_nontemporal_store(res, reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4));
+                        else *reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4) = res;
                     }
                 }
             }
         }
     }
+    if (DBG && lane == 0) dbg_w[1] = (unsigned long long)dbg_n;
 }
 
 // kernels + fix-ups of every part; `partial` = workspace base (rows of dp floats)
@@ -633,18 +760,52 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
     // row-wise layout inside 4 MiB windows 15.1 ms/step (SpMM 4.16 ms), inside 2 MiB windows with a tick every third
     // 14.3-14.4 (3.9); column order inside 8 MiB windows 13.65-13.7 (3.68-3.71), 6 MiB 13.8, 12 MiB 13.9, 16 MiB 14.3,
     // 4 MiB 14.4; lead 0: 14.9, lead 2: 14.5.
-    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 1), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
+    // r02, with the wave priorities below: lead 2 beats lead 1 by 4 % on both halves of C3 (profiles/r02_swept_lab.txt)
+    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 2), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
     const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 1));       // windows per sweep step (lab knob)
+    // lag (KiB of table slice) behind the front of its workgroup beyond which a wave raises its priority; 0 = off
+    const unsigned prio_cols = (unsigned)std::max(0, env_int("NGCF_SWEPT_PRIO_KB", 512)) * 1024u / (kSW * 4);
+    const int prio_graded = env_int("NGCF_SWEPT_PRIO_GRADED", 0);
+    const int nt_flags = env_int("NGCF_SWEPT_NT", 0);                          // 1: streaming loads of the entry lists, 2: streaming stores of the rows
+    const char *trace = getenv("NGCF_SWEPT_TRACE");
+    int part_no = 0;
     for (const auto &p : w.parts) {
         float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
-        if (p.waves == 16)
-            spmm_swept_kernel<kLdsRows / 16, 16><<<dim3(kSweptWGs), 16 * 64, 0, stream>>>(
-                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead, sync_k);
-        else
-            spmm_swept_kernel<kLdsRows / 8, 8><<<dim3(kSweptWGs), 8 * 64, 0, stream>>>(
-                p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, d / kSW, E, ldE, out, ldo, pp, dp, w.barrier, max_spin, lead, sync_k);
+        unsigned long long *dbg = nullptr;
+        const size_t dbg_words = (size_t)kSweptWGs * p.waves * (2 * kDbgSamples + 2);
+        if (trace) {
+            HIP_TRY(hipMalloc(&dbg, dbg_words * 8));
+            HIP_TRY(hipMemsetAsync(dbg, 0, dbg_words * 8, stream));
+        }
+#define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_)                                                                                  \
+    spmm_swept_kernel<RW_, NW_, DBG_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, \
+                                                                               d / kSW, E, ldE, out, ldo, pp, dp, w.barrier,   \
+                                                                               max_spin, lead, sync_k, prio_cols, prio_graded, nt_flags, dbg)
+        if (p.waves == 16) {
+            if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true);
+            else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false);
+        } else {
+            if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, true);
+            else NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false);
+        }
+#undef NGCF_SWEPT_LAUNCH
         LAUNCH_CHECK();
+        if (trace) {     // lab only: host-synchronous dump, one file per part (the last launch wins)
+            std::vector<unsigned long long> h(dbg_words);
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(h.data(), dbg, dbg_words * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(dbg);
+            char path[512];
+            snprintf(path, sizeof(path), "%s.part%d", trace, part_no);
+            if (FILE *f = fopen(path, "wb")) {
+                const long long hdr[6] = {kSweptWGs, p.waves, kDbgSamples, p.win_cols, p.n_win, p.col_lo};
+                fwrite(hdr, sizeof(hdr), 1, f);
+                fwrite(h.data(), 8, h.size(), f);
+                fclose(f);
+            }
+        }
+        ++part_no;
     }
     for (const auto &p : w.parts) {
         if (p.n_heavy == 0) continue;

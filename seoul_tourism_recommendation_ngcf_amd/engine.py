@@ -167,8 +167,8 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
     d = int(E.shape[1])
     if E.shape[0] != csr.n_cols:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({csr.n_rows}x{csr.n_cols} and {tuple(E.shape)})")
-    if out is None:     # rows padded to a multiple of 4 floats (16-byte aligned rows: the float4 kernels apply at any d)
-        out = torch.empty((csr.n_rows, (d + 3) // 4 * 4), dtype=torch.float32, device=E.device)[:, :d]
+    if out is None:     # rows padded to a multiple of 32 floats (128-byte aligned rows: the float4 / swept kernels apply at any d)
+        out = torch.empty((csr.n_rows, (d + 31) // 32 * 32), dtype=torch.float32, device=E.device)[:, :d]
     ws = ws or Workspace()
     nb = csr.spmm_workspace_bytes(d)
     w = ws.get(nb, E.device)
@@ -229,17 +229,22 @@ def layer_dense(LE: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2, carry, n
             _ptr(norm), _row_major_ld(norm, "norm"), _ptr(w), w.numel(), _stream()))
 
 
-def copy_rows(src: torch.Tensor, dst: torch.Tensor):
-    """dst[:, :] = src (strided row copy, ngcf_copy_rows_f32)."""
+def copy_rows(src: torch.Tensor, dst: torch.Tensor, dst2: Optional[torch.Tensor] = None):
+    """dst[:, :] = src (strided row copy, ngcf_copy_rows_f32); with `dst2` also dst2[:, :] = src in the same pass."""
     lib = _lib.load()
     _f32c(src, "src"), _f32c(dst, "dst")
-    if src.shape != dst.shape:
+    if src.shape != dst.shape or (dst2 is not None and dst2.shape != src.shape):
         raise RuntimeError(f"copy_rows: shape mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
     if src.shape[0] == 0:
         return
     with torch.cuda.device(dst.device):
-        _lib.check(lib.ngcf_copy_rows_f32(_ptr(src), _row_major_ld(src, "src"), _ptr(dst), _row_major_ld(dst, "dst"),
-                                          src.shape[0], src.shape[1], _stream()))
+        if dst2 is None:
+            _lib.check(lib.ngcf_copy_rows_f32(_ptr(src), _row_major_ld(src, "src"), _ptr(dst), _row_major_ld(dst, "dst"),
+                                              src.shape[0], src.shape[1], _stream()))
+        else:
+            _lib.check(lib.ngcf_copy_rows2_f32(_ptr(src), _row_major_ld(src, "src"), _ptr(dst), _row_major_ld(dst, "dst"),
+                                               _ptr(_f32c(dst2, "dst2")), _row_major_ld(dst2, "dst2"), src.shape[0],
+                                               src.shape[1], _stream()))
 
 
 def gather_rows(table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor, row_off: int = 0,
