@@ -235,6 +235,12 @@ int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, in
  * The score matrix is a plain GEMM and is left to the caller. */
 int ngcf_topk_rows_f32(const float *scores, int64_t ld, int64_t n_rows, int64_t n_cols, int k, float *out_val,
                        int64_t *out_idx, void *stream);
+/* Score-and-select in one launch (experiment.py:93,104-109; demo.py:233-235): scores[b, i] = u[b, :] . items[i, :] for every
+ * item, then top-k per user row (values descending, ties lowest item first), without a library GEMM.  u: [B, D] (ldu),
+ * items: [n_items, D] (ldi; e.g. all_items_emb, a row range of all_E), scratch: [B, ld_scratch >= n_items] floats of caller
+ * memory that receives the score matrix (it is what `torch.mm` would have returned), out_val [B, k], out_idx [B, k] int64. */
+int ngcf_recommend_topk_f32(const float *u, int64_t ldu, int64_t B, const float *items, int64_t ldi, int64_t n_items,
+                            int D, int k, float *scratch, int64_t ld_scratch, float *out_val, int64_t *out_idx, void *stream);
 
 /* ---- multi-GPU row partition (new design; host-only helper) --------------- */
 /*

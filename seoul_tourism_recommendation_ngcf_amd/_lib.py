@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ngcf_layer_bwd_weight_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp, _i64, _vp]),
     "ngcf_add_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_topk_rows_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp]),
+    "ngcf_recommend_topk_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),
     "ngcf_shard_plan": (C.c_int, [C.POINTER(_i64), _i64, _i64, C.c_int, C.POINTER(_i64)]),
     "ngcf_allgather_rows": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "ngcf_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),

@@ -124,7 +124,12 @@ __global__ void row_colrange_kernel(const int64_t *__restrict__ rowptr, const in
 // A row block is "sliceable" when one 32-float slice (128 B) of every row it gathers is at most 48 MiB: then the
 // hot part of the table slice lives in the XCD L2s while a slice-major launch walks it (measured on the user half
 // of C3: 2.33 ms sliced vs 2.98 ms unsliced; the 1 M-row user table gets slower sliced: 3.8 vs 3.46 ms).
-static const int64_t kSliceFootprintRows = (48ll << 20) / 128;
+static int64_t slice_footprint_rows()   // NGCF_SLICE_MAX_MB: lab knob (C5-sized tables: slices that fit the 256 MiB Infinity Cache)
+{
+    const char *e = getenv("NGCF_SLICE_MAX_MB");
+    return ((int64_t)(e ? atoi(e) : 48) << 20) / 128;
+}
+#define kSliceFootprintRows slice_footprint_rows()
 
 static int build_row_groups(ngcf_csr *c, hipStream_t stream)
 {

@@ -339,14 +339,20 @@ __device__ inline uint32_t float_key(float x)      // monotone map float -> uint
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void topk_rows_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_cols, int k,
-                                                        int kp2, float *__restrict__ out_val, int64_t *__restrict__ out_idx)
+struct TopkShared {
+    uint32_t hist[256];
+    uint32_t sh_prefix, sh_need, sh_cnt_gt, sh_cnt_eq;
+    uint32_t skey[NGCF_TOPK_MAX];
+    int32_t sidx[NGCF_TOPK_MAX];
+};
+
+// top-k of one score row by the 256 threads of a workgroup; writes out_val[0..k), out_idx[0..k)
+__device__ inline void topk_one_row(const float *__restrict__ row, int64_t n_cols, int k, int kp2, float *__restrict__ out_val,
+                                    int64_t *__restrict__ out_idx, TopkShared &sh)
 {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh_prefix, sh_need, sh_cnt_gt, sh_cnt_eq;
-    __shared__ uint32_t skey[NGCF_TOPK_MAX];
-    __shared__ int32_t sidx[NGCF_TOPK_MAX];
-    const float *row = scores + (int64_t)blockIdx.x * ld;
+    uint32_t *hist = sh.hist, *skey = sh.skey;
+    int32_t *sidx = sh.sidx;
+    uint32_t &sh_prefix = sh.sh_prefix, &sh_need = sh.sh_need, &sh_cnt_gt = sh.sh_cnt_gt, &sh_cnt_eq = sh.sh_cnt_eq;
     const int tid = threadIdx.x;
     // ---- radix select: after the 4 passes `prefix` is the key of the k-th largest element
     uint32_t prefix = 0, need = (uint32_t)k;      // `need` = how many of the current prefix class are still wanted
@@ -444,10 +450,88 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float *__restrict_
         }
     }
     for (int j = tid; j < k; j += 256) {
-        out_idx[(int64_t)blockIdx.x * k + j] = sidx[j];
-        out_val[(int64_t)blockIdx.x * k + j] = row[sidx[j]];
+        out_idx[j] = sidx[j];
+        out_val[j] = row[sidx[j]];
     }
+    __syncthreads();
 }
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float *__restrict__ scores, int64_t ld, int64_t n_cols, int k,
+                                                        int kp2, float *__restrict__ out_val, int64_t *__restrict__ out_idx)
+{
+    __shared__ TopkShared sh;
+    topk_one_row(scores + (int64_t)blockIdx.x * ld, n_cols, k, kp2, out_val + (int64_t)blockIdx.x * k,
+                 out_idx + (int64_t)blockIdx.x * k, sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Score-and-select in one launch (experiment.py:93,104-109: `torch.mm(u_embeds, pos_i_embeds.T)` -> topk; demo.py:233-235:
+// `torch.mm(u_embeds, all_items_emb.T)` -> topk(100)).  A workgroup owns kRecRows user rows.  Phase A: their scores against
+// every item, item tiles of 256 x 32 staged through LDS (coalesced 128-byte row segments), each thread one item x all the
+// workgroup's user rows (the user values are LDS broadcasts), written to the workgroup's rows of the score scratch.
+// Phase B: the radix select + bitonic sort above on each of those rows.  No library GEMM, no second launch.
+// ---------------------------------------------------------------------------------------------
+#define NGCF_REC_ROWS 8
+#define NGCF_REC_TK 32
+
+__global__ __launch_bounds__(256) void recommend_topk_kernel(const float *__restrict__ U, int64_t ldu, int64_t B,
+                                                             const float *__restrict__ items, int64_t ldi, int64_t n_items, int D,
+                                                             int k, int kp2, float *__restrict__ scratch, int64_t lds_,
+                                                             float *__restrict__ out_val, int64_t *__restrict__ out_idx)
+{
+    constexpr int RB = NGCF_REC_ROWS, TK = NGCF_REC_TK, TI = 256, SLD = TK + 4;   // item rows in LDS: 36 floats, b128-aligned
+    __shared__ float sI[TI * SLD];
+    __shared__ float sU[RB * TK];
+    __shared__ TopkShared sh;
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * RB;
+    const int n_b = (int)((B - b0) < RB ? (B - b0) : RB);
+    for (int64_t i0 = 0; i0 < n_items; i0 += TI) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int k0 = 0; k0 < D; k0 += TK) {
+            __syncthreads();
+            // stage: 8 consecutive threads read the 32 floats (128 B) of one item row; zero beyond the matrix
+#pragma unroll
+            for (int j = 0; j < TI * TK / 256; ++j) {
+                const int f = tid + 256 * j;
+                const int it = f / TK, kk = f % TK;
+                const int64_t gi = i0 + it;
+                sI[it * SLD + kk] = (gi < n_items && k0 + kk < D) ? items[gi * ldi + k0 + kk] : 0.f;
+            }
+            {
+                const int r = tid / TK, kk = tid % TK;           // 256 threads = RB x TK exactly
+                sU[tid] = (r < n_b && k0 + kk < D) ? U[(b0 + r) * ldu + k0 + kk] : 0.f;
+            }
+            __syncthreads();
+            const float *mine = sI + tid * SLD;
+#pragma unroll
+            for (int kq = 0; kq < TK; kq += 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(mine + kq);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const float4 u = *reinterpret_cast<const float4 *>(sU + r * TK + kq);   // broadcast
+                    acc[r] = fmaf(x.x, u.x, acc[r]);
+                    acc[r] = fmaf(x.y, u.y, acc[r]);
+                    acc[r] = fmaf(x.z, u.z, acc[r]);
+                    acc[r] = fmaf(x.w, u.w, acc[r]);
+                }
+            }
+        }
+        if (i0 + tid < n_items) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r < n_b) scratch[(b0 + r) * lds_ + i0 + tid] = acc[r];
+        }
+    }
+    __threadfence();          // the rows are re-read by other threads of this workgroup
+    __syncthreads();
+    for (int r = 0; r < n_b; ++r)
+        topk_one_row(scratch + (b0 + r) * lds_, n_items, k, kp2, out_val + (b0 + r) * k, out_idx + (b0 + r) * k, sh);
+}
+
+
 
 extern "C" int ngcf_topk_rows_f32(const float *scores, int64_t ld, int64_t n_rows, int64_t n_cols, int k, float *out_val,
                                   int64_t *out_idx, void *stream_)
@@ -460,6 +544,25 @@ extern "C" int ngcf_topk_rows_f32(const float *scores, int64_t ld, int64_t n_row
     int kp2 = 1;
     while (kp2 < k) kp2 <<= 1;
     topk_rows_kernel<<<dim3((unsigned)n_rows), 256, 0, (hipStream_t)stream_>>>(scores, ld, n_cols, k, kp2, out_val, out_idx);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+extern "C" int ngcf_recommend_topk_f32(const float *u, int64_t ldu, int64_t B, const float *items, int64_t ldi, int64_t n_items,
+                                       int D, int k, float *scratch, int64_t ld_scratch, float *out_val, int64_t *out_idx,
+                                       void *stream_)
+{
+    if (B == 0) return NGCF_OK;
+    if (!u || !items || !scratch || !out_val || !out_idx || D <= 0 || ldu < D || ldi < D || ld_scratch < n_items)
+        return fail(NGCF_ERR_ARG, "recommend_topk: bad argument");
+    if (k < 1 || k > n_items) return fail(NGCF_ERR_ARG, "selected index k out of range (k=%d, row length %lld)", k, (long long)n_items);
+    if (k > NGCF_TOPK_MAX) return fail(NGCF_ERR_ARG, "recommend_topk: k=%d > %d is not supported", k, NGCF_TOPK_MAX);
+    if (n_items >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "recommend_topk: too many items");
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
+    const int64_t blocks = (B + NGCF_REC_ROWS - 1) / NGCF_REC_ROWS;
+    recommend_topk_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream_>>>(u, ldu, B, items, ldi, n_items, D, k, kp2, scratch,
+                                                                                   ld_scratch, out_val, out_idx);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

@@ -330,10 +330,26 @@ def topk_rows(scores: torch.Tensor, k: int):
     return vals, idx
 
 
-def recommend_topk(u_emb: torch.Tensor, item_emb: torch.Tensor, k: int):
-    """Scores of every item for every user row and their top-k (experiment.py:93,104-111; demo.py:234-235):
-    the score matrix is one library GEMM, the selection the HIP radix-select kernel."""
-    return topk_rows(torch.mm(u_emb, item_emb.t()), k)
+def recommend_topk(u_emb: torch.Tensor, item_emb: torch.Tensor, k: int, return_scores: bool = False):
+    """Scores of every item for every user row and their top-k (experiment.py:93,104-111; demo.py:233-235) in ONE launch of a
+    hand-written kernel (ngcf_recommend_topk_f32): score tiles through LDS, then radix select + bitonic sort per row.
+    Returns (values [B, k], int64 indices [B, k]); with `return_scores` also the [B, n_items] score matrix (what
+    `torch.mm(u_emb, item_emb.T)` is in the reference)."""
+    lib = _lib.load()
+    _f32c(u_emb, "u_emb"), _f32c(item_emb, "item_emb")
+    if u_emb.dim() != 2 or item_emb.dim() != 2 or u_emb.shape[1] != item_emb.shape[1]:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(u_emb.shape)} and {tuple(item_emb.t().shape)})")
+    B, D, n_items = int(u_emb.shape[0]), int(u_emb.shape[1]), int(item_emb.shape[0])
+    u_emb = u_emb if u_emb.stride(1) == 1 else u_emb.contiguous()
+    item_emb = item_emb if item_emb.stride(1) == 1 else item_emb.contiguous()
+    scores = torch.empty((B, n_items), dtype=torch.float32, device=u_emb.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=u_emb.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=u_emb.device)
+    with torch.cuda.device(u_emb.device):
+        _lib.check(lib.ngcf_recommend_topk_f32(_ptr(u_emb), _row_major_ld(u_emb, "u_emb"), B, _ptr(item_emb),
+                                               _row_major_ld(item_emb, "item_emb"), n_items, D, int(k), _ptr(scores), n_items,
+                                               _ptr(vals), _ptr(idx), _stream()))
+    return (vals, idx, scores) if return_scores else (vals, idx)
 
 
 def shard_plan(rowptr_host: torch.Tensor, row_begin: int, row_end: int, world: int):

@@ -15,6 +15,11 @@ reference class; `total_df` is a pandas frame with the columns named in `cols`.
 """
 from __future__ import annotations
 
+import io
+import os
+import pickle
+from datetime import datetime
+
 import numpy as np
 import torch
 
@@ -26,10 +31,11 @@ def laplacian_slices(year, userid, itemid, rating, n_user: int, n_item: int, dev
     itemid = torch.as_tensor(itemid, dtype=torch.int64, device=device)
     rating = torch.as_tensor(rating, dtype=torch.float32, device=device)
     N = n_user + n_item
-    years = []
-    for y in year.tolist():                     # pandas .unique(): order of first appearance
-        if y not in years:
-            years.append(y)
+    # pandas .unique(): order of first appearance
+    uniq, inv = torch.unique(year, return_inverse=True)
+    first = torch.full((uniq.numel(),), year.numel(), dtype=torch.int64, device=year.device)
+    first.scatter_reduce_(0, inv, torch.arange(year.numel(), device=year.device), reduce="amin")
+    years = [int(uniq[k]) for k in torch.argsort(first).tolist()]
     # state of R: sorted unique keys (u * n_item + i) with their current value
     keys = torch.empty(0, dtype=torch.int64, device=device)
     vals = torch.empty(0, dtype=torch.float32, device=device)
@@ -82,6 +88,8 @@ class Matrix(torch.nn.Module):
         self.n_user = num_dict['user']
         self.n_item = num_dict['item']
         self.lap_list = [[] for _ in self.df['year'].unique()]
+        self.file_tag = "implicit"        # file name tag of save_data (the reference formats its CLI arguments in here)
+        self.saved_path = None
 
     def create_matrix(self):
         N = self.n_user + self.n_item
@@ -89,6 +97,53 @@ class Matrix(torch.nn.Module):
                                   self.df[self.rating_col].values, self.n_user, self.n_item, self.device)
         for yi, (r, c, v) in slices.items():
             self.lap_list[yi] = torch.sparse_coo_tensor(torch.stack([r, c]), v, (N, N))
-        if self.save_data:
-            raise NotImplementedError("pickling lap_list (matrix.py:70-75) is left to the caller: torch.save(lap_list, path)")
+        if self.save_data:                                   # matrix.py:70-75
+            self.saved_path = save_lap_list(self.lap_list, self.folder_path, self.file_tag)
         return self.lap_list
+
+
+# ------------------------------------------------------------------------------------------------
+# lap_list.pkl: the writer of matrix.py:70-75 and the reader of demo.py:22-27,63-67
+# ------------------------------------------------------------------------------------------------
+def save_lap_list(lap_list, folder_path: str, tag: str = "implicit") -> str:
+    """What `Matrix.create_matrix(save_data=True)` writes (matrix.py:70-75): `pickle.dump(lap_list, f)` - a plain pickle of
+    the list of torch sparse COO tensors, wherever they live - into `lap_list_<tag>_<month>_<day>_<hour>_<minute>.pkl` under
+    `folder_path`.  (The reference puts its argparse hyper-parameters into `<tag>`; the CLI is out of scope here, so the
+    caller chooses the tag.)  Returns the path."""
+    d1 = datetime.now()
+    path = os.path.join(folder_path, f"lap_list_{tag}_{d1.month}_{d1.day}_{d1.hour}_{d1.minute}.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(list(lap_list), f)
+    return path
+
+
+class LapListUnpickler(pickle.Unpickler):
+    """The reader of demo.py:22-27 (`CPU_Unpickler`) with an allow-list: a `lap_list` pickle only ever needs the handful of
+    torch rebuild helpers a sparse COO tensor reduces to.  Tensor storages arrive as `torch.storage._load_from_bytes(b)`;
+    like the reference's hook they are routed through `torch.load(..., map_location='cpu')` - here with `weights_only=True`,
+    so nothing in the inner blob is executed either - which is what lets a file written on a GPU machine open anywhere.
+    Any other global in the stream raises `pickle.UnpicklingError`."""
+
+    _ALLOWED = {
+        ("torch._utils", "_rebuild_sparse_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+        ("torch.serialization", "_get_layout"), ("torch", "Size"), ("collections", "OrderedDict"),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=True)
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"lap_list pickle refers to {module}.{name}, which is not needed to rebuild sparse "
+                                     "tensors: refusing to load it")
+
+
+def load_lap_list(path: str, device="cpu"):
+    """`lap_list` from a file written by `save_lap_list` / matrix.py:70-75, on the CPU (demo.py:63-67) or moved to `device`.
+    Only files this process's user trusts enough to parse: the allow-list bounds what the stream can name, it does not
+    make a hostile pickle harmless in general."""
+    with open(path, "rb") as f:
+        laps = LapListUnpickler(f).load()
+    if not isinstance(laps, list) or not all(isinstance(t, torch.Tensor) and t.is_sparse for t in laps):
+        raise pickle.UnpicklingError("not a lap_list: expected a list of torch sparse COO tensors")
+    return [t.to(device) for t in laps]

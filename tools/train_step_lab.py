@@ -36,6 +36,7 @@ for split in ("1", ""):
 for mode, node_flag, train in (("eval-mode grads, no dropout", False, False), ("train mode, device node dropout + message dropout", True, True)):
     model.train(train)
     model.node_dropout_mode = "device"
+    model.mess_dropout_mode = "device"
     for it in range(4):
         if it == 1:
             torch.cuda.synchronize(); t0 = time.perf_counter()
