@@ -760,17 +760,21 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
     // row-wise layout inside 4 MiB windows 15.1 ms/step (SpMM 4.16 ms), inside 2 MiB windows with a tick every third
     // 14.3-14.4 (3.9); column order inside 8 MiB windows 13.65-13.7 (3.68-3.71), 6 MiB 13.8, 12 MiB 13.9, 16 MiB 14.3,
     // 4 MiB 14.4; lead 0: 14.9, lead 2: 14.5.
-    // r02, with the wave priorities below: lead 2 beats lead 1 by 4 % on both halves of C3 (profiles/r02_swept_lab.txt)
-    const int lead = std::min(env_int("NGCF_SWEPT_LEAD", 2), kRing - 4);        // sweep steps a wave may run ahead (-1: no sync)
+    // r02, with the graded wave priorities below (profiles/r02_swept_lab.txt, grid of window x lead x threshold): a table of
+    // many windows wants lead 2 (C3 item rows, 16 windows: 1.50 vs 1.53 ms), a table of a few windows lead 1 (C3 user rows, 4
+    // windows: 1.44 vs 1.46 ms); NGCF_SWEPT_LEAD overrides both (-1: no synchronisation at all)
+    const int lead_env = env_int("NGCF_SWEPT_LEAD", -2);
     const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 1));       // windows per sweep step (lab knob)
     // lag (KiB of table slice) behind the front of its workgroup beyond which a wave raises its priority; 0 = off
-    const unsigned prio_cols = (unsigned)std::max(0, env_int("NGCF_SWEPT_PRIO_KB", 512)) * 1024u / (kSW * 4);
-    const int prio_graded = env_int("NGCF_SWEPT_PRIO_GRADED", 0);
+    const unsigned prio_cols = (unsigned)std::max(0, env_int("NGCF_SWEPT_PRIO_KB", 256)) * 1024u / (kSW * 4);
+    // graded: priority 1 / 2 / 3 beyond 1x / 2x / 4x the threshold (C3 item rows 1.50 vs 1.61 ms against one step to 3)
+    const int prio_graded = env_int("NGCF_SWEPT_PRIO_GRADED", 1);
     const int nt_flags = env_int("NGCF_SWEPT_NT", 0);                          // 1: streaming loads of the entry lists, 2: streaming stores of the rows
     const char *trace = getenv("NGCF_SWEPT_TRACE");
     int part_no = 0;
     for (const auto &p : w.parts) {
         float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
+        const int lead = std::min(lead_env != -2 ? lead_env : (p.n_win >= 8 ? 2 : 1), kRing - 4);   // sweep steps a wave may run ahead
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
         unsigned long long *dbg = nullptr;
         const size_t dbg_words = (size_t)kSweptWGs * p.waves * (2 * kDbgSamples + 2);

@@ -55,7 +55,12 @@ for name, (r, c, v, nr) in parts.items():
         tb = time.time() - t0
         for lead in leads:
             os.environ["NGCF_SWEPT_LEAD"] = str(lead)
-            ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
-            err = float((out - ref).abs().max())
-            print(f"{name}: swept window {kb:5d} KiB x{every} {order} waves {waves:>2s} cut T/{cut} lead {lead:2d} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  "
-                  f"(plan {tb:.1f} s, max diff {err:.1e})", flush=True)
+            # launch-time knobs of the wave priorities (LAB_PRIO: lag thresholds in KiB, LAB_GRADED: 0 / 1)
+            for prio in os.environ.get("LAB_PRIO", os.environ.get("NGCF_SWEPT_PRIO_KB", "512")).split(","):
+                for graded in os.environ.get("LAB_GRADED", "0").split(","):
+                    os.environ["NGCF_SWEPT_PRIO_KB"], os.environ["NGCF_SWEPT_PRIO_GRADED"] = prio, graded
+                    ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
+                    err = float((out - ref).abs().max())
+                    print(f"{name}: swept window {kb:5d} KiB x{every} {order} waves {waves:>2s} cut T/{cut} lead {lead:2d} prio {prio:>4s} KiB "
+                          f"graded {graded} {ms:7.3f} ms  gather {v.numel() * d * 4 / ms / 1e9:6.2f} TB/s  (plan {tb:.1f} s, max diff {err:.1e})",
+                          flush=True)

@@ -64,7 +64,7 @@ def analyse(path, label):
         spread90 = np.percentile(pos, 95, axis=0) - np.percentile(pos, 5, axis=0)
         spread_all = pos.max(axis=0) - pos.min(axis=0)
         med = np.median(pos, axis=0)
-        within = np.mean(np.abs(pos - med[None, :]) <= 1.5, axis=0)      # share of waves within +-1.5 MiB of the median
+        near = np.mean(np.abs(pos - med[None, :]) <= 1.5, axis=0)        # share of waves within +-1.5 MiB of the median
         dur_us = (hi - lo) / 100.0                                          # s_memrealtime ticks at 100 MHz
         if x == 0:      # decomposition on one XCD: between workgroups vs inside a workgroup, and who the stragglers are
             wg_of = np.array([w // waves for w in ws_ if ((np.arange(n_samp) < cnt[w]) & (sweep[w] == 0)).sum() > 3])
@@ -86,7 +86,7 @@ def analyse(path, label):
                   f"offset p1/p5/p50/p95/p99 at mid-sweep: " + " ".join(f"{np.percentile(mid - np.median(mid), q):+.1f}" for q in (1, 5, 50, 95, 99)))
         print(f"  xcd {x}: {len(series):4d} waves, common span {dur_us:7.1f} us; spread p5..p95 median {np.median(spread90):6.1f} MiB "
               f"(max {spread90.max():6.1f}), min..max median {np.median(spread_all):6.1f} MiB; waves within +-1.5 MiB of the "
-              f"median position: {100 * np.median(within):4.1f} %")
+              f"median position: {100 * np.median(near):4.1f} %")
     # start skew of the workgroups and of the waves
     starts = np.array([t[w, 0] for w in range(len(t)) if cnt[w] > 0]) - t0
     ends = np.array([t[w, cnt[w] - 1] for w in range(len(t)) if cnt[w] > 0]) - t0
