@@ -191,24 +191,40 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
     float rowss[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
+    if (!drop_mask && !(drop_p > 0.f)) {
+        // eval mode / no message dropout: the same loop without the two per-element tests of the dropout form
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = (cw * NT + t) * 32 + li;
-        const float bz = bias2[col];
+        for (int t = 0; t < NT; ++t) {
+            const int col = (cw * NT + t) * 32 + li;
+            const float bz = bias2[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[t][r] + bz;
-            v = v >= 0.f ? v : leaky * v;
-            if (drop_mask) {       // "reference" mode: the noise tensor nn.Dropout drew on the host (0 or 1/(1-p)), NGCF.py:142
-                const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
-            } else if (drop_p > 0.f) {
-                const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
-                v = h < drop_thr ? 0.f : v * keep_scale;
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r] + bz;
+                v = v >= 0.f ? v : leaky * v;
+                acc[t][r] = v;
+                rowss[r] = fmaf(v, v, rowss[r]);
             }
-            acc[t][r] = v;
-            rowss[r] = fmaf(v, v, rowss[r]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = (cw * NT + t) * 32 + li;
+            const float bz = bias2[col];
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r] + bz;
+                v = v >= 0.f ? v : leaky * v;
+                if (drop_mask) {       // "reference" mode: the noise tensor nn.Dropout drew on the host (0 or 1/(1-p)), NGCF.py:142
+                    const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
+                } else if (drop_p > 0.f) {
+                    const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                    v = h < drop_thr ? 0.f : v * keep_scale;
+                }
+                acc[t][r] = v;
+                rowss[r] = fmaf(v, v, rowss[r]);
+            }
         }
     }
     // reduce over the 32 lanes that share a row (lanes li = 0..31 within each half)
@@ -240,7 +256,28 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
             rowss[r] = s;
         }
     }
-    // ---- stores: carry (un-normalised, feeds the next layer) and the normalised all_E block
+    // ---- stores: carry (un-normalised, feeds the next layer) and the normalised all_E block.  A full tile (every row and
+    // column inside the matrix: all but the last workgroup) stores without the per-element tests.
+    if (row0 + BM <= n_rows && d_out == WCOLS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float inv = 1.f / fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
+            float *nrow = norm + grow * ldn + cw * NT * 32 + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) nrow[t * 32] = acc[t][r] * inv;
+        }
+        if (carry) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float *crow = carry + grow * ldc + cw * NT * 32 + li;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) crow[t * 32] = acc[t][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t grow = row0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
