@@ -83,6 +83,7 @@ int64_t ngcf_csr_nnz(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_rows(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_cols(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_segments(const ngcf_csr_t *csr);
+int64_t ngcf_csr_max_row_len(const ngcf_csr_t *csr);        /* stored entries of the longest row */
 /* rows currently covered by L2-swept parts (0: every product of this CSR runs on the row-wise kernels) */
 int64_t ngcf_csr_swept_rows(const ngcf_csr_t *csr);
 /* device pointers of the CSR arrays (for tests / the transposed view) */
@@ -211,7 +212,21 @@ int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, i
  * dC (gradient of the carry from the next layer, may be NULL) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
                            int64_t n_rows, int d, float leaky_slope, float drop_p, uint64_t drop_seed,
-                           const float *drop_mask, int64_t ld_mask, float *dM, int64_t ldm, void *stream);
+                           const float *drop_mask, int64_t ld_mask, const int64_t *row_ids, float *dM, int64_t ldm, void *stream);
+/* (row_ids: NULL, or the matrix rows the n_rows compacted rows stand for - they index the hash stream of device-mode dropout) */
+/* out[c, :] += v * X[i, :] for every stored entry (rows[i], c, v) of `csr`: L^T . X for a row-sparse X given by its n_sel
+ * non-zero rows (float atomics; `out` must hold the other summands or zeros).  max_row_len: longest row of the CSR (sizes the
+ * grid).  drop_p / seeds: device-side node dropout as in ngcf_spmm_csr_dropout_f32 (entry numbers = positions in `csr`). */
+int ngcf_spmm_scatter_rows_f32(const ngcf_csr_t *csr, const int64_t *rows, int64_t n_sel, int64_t max_row_len, const float *X,
+                               int64_t ldx, int d, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
+                               void *stream);
+/* Input gradients of a layer's dense half in one MFMA kernel: dS = dM.W1, dP = dM.W2 (never stored), dLE = dS + dP*E,
+ * dE_direct = dS + dP*LE (NGCF.py:131-136 differentiated).  dM: [n_rows, d_out] with 16-byte aligned rows padded to a
+ * multiple of 4 floats; W1, W2: [d_out, d_in] row-major (nn.Linear.weight); LE, E, dLE, dE: [n_rows, d_in]. */
+int64_t ngcf_layer_bwd_input_workspace_bytes(int d_out);
+int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_rows, int d_out, const float *W1, const float *W2,
+                             int d_in, const float *LE, int64_t ldLE, const float *E, int64_t ldE, float *dLE, int64_t ldd,
+                             float *dE, int64_t lde, void *workspace, int64_t workspace_bytes, void *stream);
 /* SP[n_rows, 2d] = [LE + E | LE * E], the forward GEMM operand (NGCF.py:131-136), needed for dW1/dW2. */
 int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ldE, int64_t n_rows, int d, float *SP,
                        void *stream);

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "ngcf_csr_n_rows": (_i64, [_vp]),
     "ngcf_csr_n_cols": (_i64, [_vp]),
     "ngcf_csr_n_segments": (_i64, [_vp]),
+    "ngcf_csr_max_row_len": (_i64, [_vp]),
     "ngcf_csr_swept_rows": (_i64, [_vp]),
     "ngcf_csr_rowptr": (_vp, [_vp]),
     "ngcf_csr_colidx": (_vp, [_vp]),
@@ -58,7 +59,11 @@ PROTOTYPES = {
     "ngcf_bpr_backward_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ngcf_scatter_add_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "ngcf_layer_bwd_pre_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _f32, _f32, _u64, _vp, _i64,
-                                         _vp, _i64, _vp]),
+                                         _vp, _vp, _i64, _vp]),
+    "ngcf_spmm_scatter_rows_f32": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, _vp]),
+    "ngcf_layer_bwd_input_workspace_bytes": (_i64, [C.c_int]),
+    "ngcf_layer_bwd_input_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
+                                           _vp, _i64, _vp]),
     "ngcf_sp_concat_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     "ngcf_layer_bwd_combine_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_bwd_weight_workspace_bytes": (_i64, []),

@@ -18,6 +18,10 @@ from . import engine as _eng
 from .engine import _ptr, _row_major_ld, _stream
 
 
+SPARSE_LAST_LAYER = True        # row-sparse backward of the last layer (Propagate.backward); False: always the dense path
+sparse_last_layer_calls = 0     # how often the row-sparse path ran (tests)
+
+
 def _write_e0(owner, user_w, item_w, all_E, U, d0):
     """E0 into its column block of all_E (the `cat` of NGCF.py:120 and of NGCF.py:147); returns E0 as the first layer
     reads it.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130, 515), so D is usually not a
@@ -85,7 +89,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
 # ------------------------------------------------------------------------------------------------
 # thin wrappers of the backward entry points
 # ------------------------------------------------------------------------------------------------
-def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None):
+def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None, row_ids=None):
     lib = _lib.load()
     n_rows, d = Cc.shape
     dM = torch.empty((n_rows, d), dtype=torch.float32, device=Cc.device)
@@ -94,7 +98,7 @@ def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None):
                                               0 if dC is None else _row_major_ld(dC, "dC"), _ptr(Cc),
                                               _row_major_ld(Cc, "C"), n_rows, d, leaky, float(drop_p), int(seed),
                                               _ptr(mask), 0 if mask is None else _row_major_ld(mask, "drop_mask"),
-                                              _ptr(dM), d, _stream()))
+                                              _ptr(row_ids), _ptr(dM), d, _stream()))
     return dM
 
 
@@ -146,6 +150,23 @@ def _bwd_combine(dSP, LE, E):
     return dLE, dE
 
 
+def _bwd_input(dM, w1, w2, LE, E, ws):
+    """dLE, dE_direct from dM in one MFMA kernel (ngcf_layer_bwd_input_f32): dM.[W1|W2] and its combination with E / LE."""
+    lib = _lib.load()
+    n_rows, d_out = dM.shape
+    d_in = int(LE.shape[1])
+    d4 = (d_in + 31) // 32 * 32   # 128-byte aligned rows: L^T . dLE then runs on the float4 / swept kernels at any width
+    dLE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d_in]
+    dE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d_in]
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    w = ws.get(int(lib.ngcf_layer_bwd_input_workspace_bytes(d_out)), dM.device)
+    with torch.cuda.device(dM.device):
+        _lib.check(lib.ngcf_layer_bwd_input_f32(_ptr(dM), _row_major_ld(dM, "dM"), n_rows, d_out, _ptr(w1), _ptr(w2), d_in,
+                                                _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E), _row_major_ld(E, "E"),
+                                                _ptr(dLE), d4, _ptr(dE), d4, _ptr(w), w.numel(), _stream()))
+    return dLE, dE
+
+
 def _add_rows(out, add):
     lib = _lib.load()
     with torch.cuda.device(out.device):
@@ -180,7 +201,7 @@ class Propagate(torch.autograd.Function):
             carries.append(carry)
             prev = carry
             off += d_out
-        ctx.owner, ctx.csrs_t, ctx.drop, ctx.seeds, ctx.n_layer = owner, csrs_t, drop, seeds, n_layer
+        ctx.owner, ctx.csrs, ctx.csrs_t, ctx.drop, ctx.seeds, ctx.n_layer = owner, csrs, csrs_t, drop, seeds, n_layer
         ctx.edge_drops, ctx.masks = edge_drops, masks
         ctx.widths, ctx.U = widths, U
         ctx.save_for_backward(all_E, *les, *carries, *[p.detach() for p in params])
@@ -199,19 +220,51 @@ class Propagate(torch.autograd.Function):
         gw1, gb1, gw2, gb2 = [None] * n, [None] * n, [None] * n, [None] * n
         dC = None
         offs = [sum(widths[:k + 1]) for k in range(n)]
+        # The gradient that reaches all_E from the row gathers is non-zero on at most 3 B rows (GatherTriple tags it with
+        # them).  The LAST layer's backward then involves those rows only: normalise/LeakyReLU backward, both weight
+        # gradients and the input gradients on a compacted [R, d] problem, and L^T . dLE as a scatter over the stored entries of
+        # those R rows of L (ngcf_spmm_scatter_rows_f32: ~1 M entries instead of 100 M on C3) - instead of a full SpMM and four
+        # passes over 1.1 M rows.  Earlier layers are dense (their dC is).
+        sparse_rows = getattr(g_all, "_ngcf_rows", None) if SPARSE_LAST_LAYER else None
         for k in reversed(range(n)):
             d_in, d_out = widths[k], widths[k + 1]
             E_k = all_E[:, :widths[0]] if k == 0 else carries[k - 1]
             LE_k, C_k = les[k], carries[k]
-            dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
-                          None if ctx.masks is None else ctx.masks[k])
+            mask_k = None if ctx.masks is None else ctx.masks[k]
+            if dC is None and sparse_rows is not None:
+                global sparse_last_layer_calls
+                sparse_last_layer_calls += 1
+                rows = sparse_rows
+                dM = _bwd_pre(g_all[rows, offs[k]:offs[k] + d_out], None, C_k[rows], _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
+                              None if mask_k is None else mask_k[rows], rows)
+                LE_c, E_c = LE_k[rows], E_k[rows]
+                gW = _bwd_weight(dM, LE_c, E_c, ws)
+                gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
+                gb = dM.sum(0)
+                gb1[k], gb2[k] = 2.0 * gb, gb
+                if d_out % 4 == 0 and d_out >= 4:
+                    dLE_c, dE_c = _bwd_input(dM, w1[k], w2[k], LE_c, E_c, ws)
+                else:
+                    dLE_c, dE_c = _bwd_combine(dM.mm(torch.cat((w1[k], w2[k]), dim=1)), LE_c, E_c)
+                d4 = (d_in + 31) // 32 * 32
+                dE = torch.zeros((all_E.shape[0], d4), dtype=torch.float32, device=all_E.device)[:, :d_in]
+                dE[rows] = dE_c
+                ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1])
+                _eng.spmm_scatter_rows(ctx.csrs[k], rows, dLE_c, dE, ed)         # dE += (thinned L)^T . dLE
+                dC = dE
+                continue
+            dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k], mask_k)
             gW = _bwd_weight(dM, LE_k, E_k, ws)                                  # MFMA kernel, operand formed on the fly
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
             gb = dM.sum(0)
             gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
-            dSP = dM.mm(torch.cat((w1[k], w2[k]), dim=1))                        # library GEMM: [N, 2 d_in]
-            dLE, dE = _bwd_combine(dSP, LE_k, E_k)
-            del dSP, dM
+            if d_out % 4 == 0 and d_out >= 4:                                    # dM rows are contiguous [N, d_out]: 16-byte aligned
+                dLE, dE = _bwd_input(dM, w1[k], w2[k], LE_k, E_k, ws)             # one MFMA kernel, dS/dP never stored
+            else:
+                dSP = dM.mm(torch.cat((w1[k], w2[k]), dim=1))                    # odd widths: library GEMM [N, 2 d_in] + combine
+                dLE, dE = _bwd_combine(dSP, LE_k, E_k)
+                del dSP
+            del dM
             ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], ctx.csrs_t[k].eid)
             _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed))     # dE += (thinned L)^T . dLE
             dC = dE
@@ -248,6 +301,9 @@ class GatherTriple(torch.autograd.Function):
                     continue
                 g = g.contiguous()
                 _lib.check(lib.ngcf_scatter_add_rows_f32(_ptr(G), D, D, _ptr(ix), ix.numel(), off, lim, _ptr(g), D, _stream()))
+        # the rows G is non-zero on (sorted, unique; one host sync for the count): if this tensor reaches Propagate.backward
+        # as it is - no other consumer of all_E added to it - the last layer's backward runs on those rows only
+        G._ngcf_rows = torch.unique(torch.cat([ix + off for ix, off in zip(idx, offs)]))
         return (G, None, None, None, None, None)
 
 

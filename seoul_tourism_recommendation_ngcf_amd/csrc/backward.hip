@@ -96,10 +96,12 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
                                                             const float *__restrict__ C, int64_t ldC, int64_t n_rows,
                                                             int d, float leaky, float drop_p, uint64_t seed,
                                                             const float *__restrict__ drop_mask, int64_t ldk,
+                                                            const int64_t *__restrict__ row_ids,
                                                             float *__restrict__ dM, int64_t ldm)
 {
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
+    const int64_t r_hash = row_ids ? row_ids[r] : r;         // compacted rows: the hash stream is indexed by the row of the matrix
     const int lane = threadIdx.x & 63;
     const float *c = C + r * ldC, *g = dN + r * ldn;
     float ss = 0.f, dot = 0.f;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
         if (drop_mask) {
             t *= drop_mask[r * ldk + j];                      // the host-drawn noise tensor of the forward (0 or 1/(1-p))
         } else if (drop_p > 0.f) {
-            const uint32_t h = mix32(seed ^ ((uint64_t)r * 0x9E3779B97F4A7C15ULL + (uint64_t)j));
+            const uint32_t h = mix32(seed ^ ((uint64_t)r_hash * 0x9E3779B97F4A7C15ULL + (uint64_t)j));
             t = h < thr ? 0.f : t * keep_scale;
         }
         dM[r * ldm + j] = t * (c[j] > 0.f ? 1.f : leaky);     // sign(C) == sign(M) wherever C was kept
@@ -130,13 +132,13 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
 
 extern "C" int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
                                       int64_t n_rows, int d, float leaky, float drop_p, uint64_t seed, const float *drop_mask,
-                                      int64_t ld_mask, float *dM, int64_t ldm, void *stream_)
+                                      int64_t ld_mask, const int64_t *row_ids, float *dM, int64_t ldm, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows == 0) return NGCF_OK;
     if (!dN || !C || !dM || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_pre: bad argument");
     layer_bwd_pre_kernel<<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
-                                                                                 seed, drop_mask, ld_mask, dM, ldm);
+                                                                                 seed, drop_mask, ld_mask, row_ids, dM, ldm);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -350,6 +352,245 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
     LAUNCH_CHECK();
     const int total = d_out * 2 * d_in;
     bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, kBwWGs, d_in, d_out, P, gW);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
+
+// =============================================================================================
+// Input gradients of a layer's dense half in one kernel (r02; replaces a library GEMM + the combine kernel and the
+// [N, 2 d_in] intermediate between them):
+//   dS = dM . W1,  dP = dM . W2                     ([n_rows, d_in] each; W1, W2 are nn.Linear weights [d_out, d_in])
+//   dLE = dS + dP * E,   dE = dS + dP * LE          (NGCF.py:131-136 differentiated)
+// Same structure as layer_dense_kernel (dense.hip): a workgroup of 4 waves owns 128 rows, each wave a 32 x 128 output
+// panel as four 32x32 tiles of v_mfma_f32_32x32x2_f32; K = d_out is walked in chunks of 32 through double-buffered LDS
+// (A: rows of dM, B: the weight rows W[k, col0 .. col0+128), which need no transpose).  The K loop runs twice over the same
+// rows of dM (second read from L2), once per weight matrix, so that both 64-register accumulators are live only in the
+// epilogue, where a lane holds dS and dP of the same (row, column) and forms both outputs.
+// =============================================================================================
+#define NGCF_BI_KC 32
+static constexpr int kBiRows = 128, kBiMaxCols = 160;
+
+// Wp[half][chunk][k][c] = W_half[chunk * 32 + k][col0 + c], c < wcols   (zero outside the matrix)
+__global__ void bwd_input_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int d_out, int d_in, int col0,
+                                      int wcols, int n_chunks, float *__restrict__ Wp)
+{
+    const int per_half = n_chunks * NGCF_BI_KC * wcols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * per_half; i += gridDim.x * blockDim.x) {
+        const int half = i / per_half, x = i % per_half;
+        const int c = x % wcols, k = x / wcols;
+        const int col = col0 + c;
+        Wp[i] = (k < d_out && col < d_in) ? (half ? W2 : W1)[(int64_t)k * d_in + col] : 0.f;
+    }
+}
+
+// NT 32x32 tiles per wave: a panel of 32*NT input columns (NT = 4: 128; NT = 5: 160, which takes the reference's 130-wide
+// first layer in one panel instead of two)
+template <int NT>
+__global__ __launch_bounds__(256) void layer_bwd_input_kernel(const float *__restrict__ dM, int64_t ldM, int64_t n_rows, int d_out,
+                                                              const float *__restrict__ Wp, int n_chunks,
+                                                              const float *__restrict__ LE, int64_t ldLE,
+                                                              const float *__restrict__ E, int64_t ldE, int d_in, int col0,
+                                                              float *__restrict__ dLE, int64_t ldd, float *__restrict__ dE, int64_t lde)
+{
+    constexpr int BM = kBiRows, WCOLS = 32 * NT, XLD = NGCF_BI_KC + 4;
+    __shared__ float Xs[2 * BM * XLD];
+    __shared__ float Ws[2 * NGCF_BI_KC * WCOLS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int d4 = (d_out + 3) & ~3;
+    bw_f32x16 acc[2][NT];
+    bw_f32x4 xreg[4], wreg[NT];
+
+    auto load_chunk = [&](int half, int chunk) {      // global -> registers (rows past the end re-read the last row, never stored)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+            int64_t grow = row0 + f / 8;
+            grow = grow < n_rows ? grow : n_rows - 1;
+            const int c0 = chunk * NGCF_BI_KC + (f % 8) * 4;
+            const int cc = c0 < d4 ? c0 : d4 - 4;
+            bw_f32x4 a = *reinterpret_cast<const bw_f32x4 *>(dM + grow * ldM + cc);
+            a.x = c0 < d_out ? a.x : 0.f;
+            a.y = c0 + 1 < d_out ? a.y : 0.f;
+            a.z = c0 + 2 < d_out ? a.z : 0.f;
+            a.w = c0 + 3 < d_out ? a.w : 0.f;
+            xreg[j] = a;
+        }
+        const bw_f32x4 *src = reinterpret_cast<const bw_f32x4 *>(Wp + ((int64_t)half * n_chunks + chunk) * NGCF_BI_KC * WCOLS);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wreg[j] = src[tid + 256 * j];       // 32 x WCOLS floats = NT float4 per thread
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+            *reinterpret_cast<bw_f32x4 *>(Xs + buf * (BM * XLD) + (f / 8) * XLD + (f % 8) * 4) = xreg[j];
+        }
+        bw_f32x4 *dst = reinterpret_cast<bw_f32x4 *>(Ws + buf * (NGCF_BI_KC * WCOLS));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) dst[tid + 256 * j] = wreg[j];
+    };
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[half][t][r] = 0.f;
+        load_chunk(half, 0);
+        store_chunk(0);                                // (the previous half's loop ended with a barrier)
+        __syncthreads();
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const bool more = chunk + 1 < n_chunks;
+            if (more) load_chunk(half, chunk + 1);      // global loads fly under the MFMAs
+            const int buf = chunk & 1;
+            const float *X = Xs + buf * (BM * XLD) + (wave * 32 + li) * XLD + lh * 4;
+            const float *W = Ws + buf * (NGCF_BI_KC * WCOLS) + li;
+#pragma unroll
+            for (int kb = 0; kb < NGCF_BI_KC / 8; ++kb) {
+                const bw_f32x4 a4 = *reinterpret_cast<const bw_f32x4 *>(X + kb * 8);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) {
+                    const float *wk = W + (kb * 8 + lh * 4 + sx) * WCOLS;
+                    float bv[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bv[t] = wk[t * 32];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[half][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], bv[t], acc[half][t], 0, 0, 0);
+                }
+            }
+            if (more) store_chunk((chunk + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // epilogue: dLE = dS + dP * E, dE = dS + dP * LE
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t grow = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= n_rows) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = col0 + t * 32 + li;
+            if (col < d_in) {
+                const float ds = acc[0][t][r], dp = acc[1][t][r];
+                dLE[grow * ldd + col] = fmaf(dp, E[grow * ldE + col], ds);
+                dE[grow * lde + col] = fmaf(dp, LE[grow * ldLE + col], ds);
+            }
+        }
+    }
+}
+
+extern "C" int64_t ngcf_layer_bwd_input_workspace_bytes(int d_out)
+{
+    if (d_out <= 0) return -1;
+    const int64_t n_chunks = (d_out + NGCF_BI_KC - 1) / NGCF_BI_KC;
+    return align_up(2 * n_chunks * NGCF_BI_KC * kBiMaxCols * (int64_t)sizeof(float), 256) + 256;
+}
+
+extern "C" int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_rows, int d_out, const float *W1, const float *W2,
+                                        int d_in, const float *LE, int64_t ldLE, const float *E, int64_t ldE, float *dLE,
+                                        int64_t ldd, float *dE, int64_t lde, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows == 0) return NGCF_OK;
+    if (!dM || !W1 || !W2 || !LE || !E || !dLE || !dE || d_in <= 0 || d_out < 4 || ldM < d_out || ldLE < d_in || ldE < d_in ||
+        ldd < d_in || lde < d_in)
+        return fail(NGCF_ERR_ARG, "layer_bwd_input: bad argument");
+    if (ldM % 4 != 0 || !aligned16(dM) || ldM < align_up(d_out, 4))
+        return fail(NGCF_ERR_ARG, "layer_bwd_input: dM needs 16-byte aligned rows padded to a multiple of 4 floats");
+    const int64_t need = ngcf_layer_bwd_input_workspace_bytes(d_out);
+    if (!workspace || workspace_bytes < need)
+        return fail(NGCF_ERR_WORKSPACE, "layer_bwd_input: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    float *Wp = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    const int n_chunks = (d_out + NGCF_BI_KC - 1) / NGCF_BI_KC;
+    const int64_t blocks = (n_rows + kBiRows - 1) / kBiRows;
+    if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "layer_bwd_input: too many rows");
+    for (int col0 = 0; col0 < d_in;) {      // panels of 128 input columns, the last one up to 160 (stream-ordered re-use of Wp)
+        const int left = d_in - col0;
+        const int wcols = left > 128 && left <= 160 ? 160 : 128;
+        bwd_input_pack_kernel<<<64, 256, 0, stream>>>(W1, W2, d_out, d_in, col0, wcols, n_chunks, Wp);
+        LAUNCH_CHECK();
+        if (wcols == 160)
+            layer_bwd_input_kernel<5><<<dim3((unsigned)blocks), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE, E, ldE,
+                                                                                  d_in, col0, dLE, ldd, dE, lde);
+        else
+            layer_bwd_input_kernel<4><<<dim3((unsigned)blocks), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE, E, ldE,
+                                                                                  d_in, col0, dLE, ldd, dE, lde);
+        LAUNCH_CHECK();
+        col0 += wcols;
+    }
+    return NGCF_OK;
+}
+
+
+// =============================================================================================
+// L^T . X for a ROW-SPARSE X (r02).  The gradient that reaches the last layer comes from the three row gathers only
+// (NGCF.py:151-155): dLE of that layer is non-zero on at most 3 B rows, so out = L^T . dLE needs only the stored entries
+// of those rows of L (column r of L^T is row r of L): out[c, :] += v * X[i, :] for every entry (rows[i], c, v).
+// ~1 M entries instead of 100 M on C3 at B = 1024.  One workgroup per (row, 2048-entry segment); a wave takes 64 entries at
+// a time and adds 256-byte pieces with float atomics (memory-side, ~1.3 TB/s chip-wide): the order of the additions into
+// one output element is not fixed, like the index_put_ / scatter_add gradients of the reference on a GPU.
+// =============================================================================================
+static constexpr int kScatSeg = 2048;
+
+__global__ __launch_bounds__(256) void spmm_scatter_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                                const float *__restrict__ vals, const int64_t *__restrict__ rows,
+                                                                int64_t n_sel, int64_t n_rows, const float *__restrict__ X, int64_t ldx,
+                                                                int d, float *__restrict__ out, int64_t ldo, EdgeDrop dr)
+{
+    const int64_t i = blockIdx.x;
+    if (i >= n_sel) return;
+    const int64_t row = rows[i];
+    if (row < 0 || row >= n_rows) return;
+    const int64_t b0 = rowptr[row] + (int64_t)blockIdx.y * kScatSeg;
+    const int64_t b1 = min(rowptr[row + 1], b0 + kScatSeg);
+    if (b0 >= b1) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float x[8];                                            // this lane's columns lane, lane+64, ... of X[i, :]  (d <= 512)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = lane + 64 * q < d ? X[i * ldx + lane + 64 * q] : 0.f;
+    for (int64_t base = b0 + wave * 64; base < b1; base += 256) {
+        const int cnt = (int)min<int64_t>(64, b1 - base);
+        int c = 0;
+        float v = 0.f;
+        if (lane < cnt) {
+            c = colidx[base + lane];
+            v = vals[base + lane];
+            if (dr.n > 0) {                                  // device-side node dropout: the same keep test as the forward SpMM
+                const uint64_t e = (uint64_t)(dr.eid ? dr.eid[base + lane] : base + lane) * 0x9E3779B97F4A7C15ULL;
+                bool keep = true;
+                for (int q = 0; q < dr.n; ++q) keep = keep && mix32(dr.seed[q] ^ e) >= dr.thr;
+                v = keep ? v : 0.f;
+            }
+        }
+        for (int j = 0; j < cnt; ++j) {
+            const int cj = __shfl(c, j);
+            const float vj = __shfl(v, j);
+            if (vj == 0.f) continue;                          // dropped entry (wave-uniform)
+            float *o = out + (int64_t)cj * ldo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (lane + 64 * q < d) atomicAdd(o + lane + 64 * q, vj * x[q]);
+        }
+    }
+}
+
+extern "C" int ngcf_spmm_scatter_rows_f32(const ngcf_csr_t *c, const int64_t *rows, int64_t n_sel, int64_t max_row_len, const float *X,
+                                          int64_t ldx, int d, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
+                                          void *stream_)
+{
+    if (!c) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: null csr");
+    if (n_sel == 0 || max_row_len <= 0) return NGCF_OK;
+    if (!rows || !X || !out || d <= 0 || d > 512 || ldx < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: bad argument (d <= 512)");
+    if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: 0..4 seeds expected");
+    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, nullptr};
+    for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
+    const int64_t segs = (max_row_len + kScatSeg - 1) / kScatSeg;
+    if (n_sel >= (int64_t)1 << 31 || segs > 65535) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: too many rows / too long a row");
+    spmm_scatter_rows_kernel<<<dim3((unsigned)n_sel, (unsigned)segs), 256, 0, (hipStream_t)stream_>>>(
+        c->rowptr, c->colidx, c->vals, rows, n_sel, c->n_rows, X, ldx, d, out, ldo, dr);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

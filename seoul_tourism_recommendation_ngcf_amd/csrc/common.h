@@ -67,6 +67,7 @@ inline int grid_for(int64_t n, int block)
 // ---------------------------------------------------------------------------------------------
 struct ngcf_csr {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t max_row_len = 0;     // stored entries of the longest row (set by the segmentation plan)
     int64_t *rowptr = nullptr;   // device [n_rows+1]
     int32_t *colidx = nullptr;   // device [nnz]
     float *vals = nullptr;       // device [nnz]

@@ -46,6 +46,7 @@ extern "C" int64_t ngcf_csr_nnz(const ngcf_csr_t *c) { return c ? c->nnz : -1; }
 extern "C" int64_t ngcf_csr_n_rows(const ngcf_csr_t *c) { return c ? c->n_rows : -1; }
 extern "C" int64_t ngcf_csr_n_cols(const ngcf_csr_t *c) { return c ? c->n_cols : -1; }
 extern "C" int64_t ngcf_csr_n_segments(const ngcf_csr_t *c) { return c ? c->n_seg : -1; }
+extern "C" int64_t ngcf_csr_max_row_len(const ngcf_csr_t *c) { return c ? c->max_row_len : -1; }
 extern "C" int64_t ngcf_csr_swept_rows(const ngcf_csr_t *c)
 {
     if (!c) return -1;
@@ -197,8 +198,10 @@ extern "C" int ngcf_csr_plan(ngcf_csr_t *c, int32_t seg_len, void *stream_)
     std::vector<int32_t> seg_row, heavy_row;
     std::vector<int64_t> seg_begin, heavy_ptr;
     heavy_ptr.push_back(0);
+    c->max_row_len = 0;
     for (int64_t r = 0; r < c->n_rows; ++r) {
         const int64_t len = rp[r + 1] - rp[r];
+        c->max_row_len = std::max(c->max_row_len, len);
         if (len > seg_len) {
             heavy_row.push_back((int32_t)r);
             for (int64_t b = rp[r]; b < rp[r + 1]; b += seg_len) {

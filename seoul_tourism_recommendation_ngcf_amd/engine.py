@@ -58,6 +58,11 @@ class LaplacianCSR:
         self.n_cols = int(lib.ngcf_csr_n_cols(self._h))
         self.nnz = int(lib.ngcf_csr_nnz(self._h))
 
+    @property
+    def max_row_len(self) -> int:
+        """Stored entries of the longest row."""
+        return int(_lib.load().ngcf_csr_max_row_len(self._h))
+
     # -- constructors ---------------------------------------------------------------------
     @classmethod
     def from_coo(cls, rows: torch.Tensor, cols: torch.Tensor, vals: torch.Tensor, n_rows: int, n_cols: int):
@@ -183,6 +188,23 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
                                                      _row_major_ld(out, "out"), float(p), arr, len(seeds), _ptr(eid),
                                                      _ptr(w), w.numel(), _stream()))
     return out
+
+
+def spmm_scatter_rows(csr: LaplacianCSR, rows: torch.Tensor, X: torch.Tensor, out: torch.Tensor, edge_drop=None):
+    """out[c, :] += v * X[i, :] for every stored entry (rows[i], c, v) of `csr` (ngcf_spmm_scatter_rows_f32): `L^T . dLE` for a
+    dLE that is non-zero on the rows `rows` only (the last layer's backward).  `edge_drop = (seeds, p)`: device-side node
+    dropout of the forward product."""
+    lib = _lib.load()
+    _f32c(X, "X"), _f32c(out, "out")
+    rows = rows.to(device=X.device, dtype=torch.int64).contiguous()
+    if X.shape[0] != rows.numel() or out.shape[0] != csr.n_cols or X.shape[1] != out.shape[1]:
+        raise RuntimeError("spmm_scatter_rows: shape mismatch")
+    seeds, p = edge_drop if edge_drop is not None else ((), 0.0)
+    arr = (C.c_uint64 * max(len(seeds), 1))(*[int(x) & (2 ** 64 - 1) for x in seeds])
+    with torch.cuda.device(X.device):
+        _lib.check(lib.ngcf_spmm_scatter_rows_f32(csr._h, _ptr(rows), rows.numel(), csr.max_row_len, _ptr(X), _row_major_ld(X, "X"),
+                                                  int(X.shape[1]), _ptr(out), _row_major_ld(out, "out"), float(p), arr, len(seeds),
+                                                  _stream()))
 
 
 def layer_fused(csr: LaplacianCSR, E_gather: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2,

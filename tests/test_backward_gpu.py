@@ -157,3 +157,61 @@ def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
     scale = max(float(want.abs().max()), 1.0) if n_rows else 1.0
     assert float((got.double() - want).abs().max()) <= 2e-5 * scale
     assert torch.equal(got, autograd._bwd_weight(dM, LE, E, ws))        # fixed summation order
+
+
+@pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(1, 4, 4, False), (130, 128, 128, False), (1000, 130, 128, True), (333, 65, 64, True),
+                                                        (257, 160, 96, False), (500, 300, 128, False), (64, 515, 512, True)])
+def test_fused_input_gradient_kernel_vs_torch(n_rows, d_in, d_out, strided, dev):
+    """ngcf_layer_bwd_input_f32: dLE = dM.W1 + (dM.W2)*E, dE = dM.W1 + (dM.W2)*LE, one MFMA kernel per 128/160-column panel."""
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    eng = _pkg().engine
+    g = torch.Generator().manual_seed(n_rows + d_in)
+    dM = (torch.randn((n_rows, d_out), generator=g) * 0.3).to(dev)
+    W1, W2 = ((torch.randn((d_out, d_in), generator=g) * 0.1).to(dev) for _ in range(2))
+    if strided:      # LE / E as column slices of wider matrices (all_E blocks, padded LE)
+        LE = (torch.randn((n_rows, d_in + 30), generator=g) * 0.5).to(dev)[:, :d_in]
+        E = (torch.randn((n_rows, d_in + 7), generator=g) * 0.5).to(dev)[:, 3:3 + d_in]
+    else:
+        LE, E = ((torch.randn((n_rows, d_in), generator=g) * 0.5).to(dev) for _ in range(2))
+    dLE, dE = ag._bwd_input(dM, W1, W2, LE, E, eng.Workspace())
+    dS, dP = dM.double() @ W1.double(), dM.double() @ W2.double()
+    scale = float(dS.abs().max()) + 1e-12
+    np.testing.assert_allclose(dLE.cpu().numpy(), (dS + dP * E.double()).cpu().numpy(), atol=2e-6 * max(scale, 1.0), rtol=2e-5)
+    np.testing.assert_allclose(dE.cpu().numpy(), (dS + dP * LE.double()).cpu().numpy(), atol=2e-6 * max(scale, 1.0), rtol=2e-5)
+
+
+@pytest.mark.parametrize("node_mode", [None, "reference", "device"])
+def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
+    """The last layer's backward on the <= 3 B gathered rows only (compacted dense kernels + ngcf_spmm_scatter_rows_f32 for
+    L^T . dLE) against the dense path (full SpMM on the transposed CSR): same gradients up to the order of the atomic adds;
+    with and without node dropout (thinned matrices in both modes) and with device-mode message dropout (hash by matrix row)."""
+    pkg = _pkg()
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    coo = pkg.graphs.synthetic_bipartite(4000, 300, 60000, seed=8, device=dev)
+    num_dict = {"user": 4000, "item": 300, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    B = 200
+    g = torch.Generator().manual_seed(4)
+    r = lambda hi: torch.randint(0, hi, (B,), generator=g).to(dev)  # noqa: E731
+    batch = dict(year=torch.full((B,), 18, device=dev), u_id=r(4000), age=r(76), sex=r(2), month=r(13), day=r(32), dow=r(7),
+                 pos_item=r(300), neg_item=r(300))
+    batch["pos_item"][:20] = 0                                     # a heavy item row several times, duplicates in the batch
+    grads = []
+    for sparse in (True, False):
+        torch.manual_seed(21)
+        model = pkg.NGCF(130, [128, 64], 0.3, [0.2, 0.2], 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, B, dev).to(dev)
+        model.train()
+        model.mess_dropout_mode = "device"
+        if node_mode:
+            model.node_dropout_mode = node_mode
+        ag.SPARSE_LAST_LAYER = sparse
+        before = ag.sparse_last_layer_calls
+        torch.manual_seed(5)                                       # same masks / seeds in both runs
+        u, p, n = model(node_flag=node_mode is not None, **batch)
+        pkg.BPR(0.025, B)(u, p, n).backward()
+        assert (ag.sparse_last_layer_calls - before) == (1 if sparse else 0)
+        grads.append({k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None})
+    ag.SPARSE_LAST_LAYER = True
+    assert set(grads[0]) == set(grads[1]) and "w1_list.1.weight" in grads[0] and "user_embedding.weight" in grads[0]
+    for k in grads[0]:
+        scale = float(grads[1][k].abs().max()) + 1e-12
+        np.testing.assert_allclose(grads[0][k].cpu().numpy(), grads[1][k].cpu().numpy(), atol=2e-5 * scale, rtol=1e-4, err_msg=k)
