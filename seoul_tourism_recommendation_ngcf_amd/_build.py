@@ -28,6 +28,7 @@ def _hipcc() -> str:
 
 
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function", "-ldl"]
+FLAGS += os.environ.get("NGCF_EXTRA_HIPCC_FLAGS", "").split()      # lab builds (e.g. -DNGCF_DC=8); part of the source hash
 STAMP = LIB + ".srchash"       # content hash of the sources the library was built from (travels with the .so)
 
 

@@ -13,8 +13,10 @@
 // so a whole output row (<= 32*NT*CW columns) lives in one workgroup and the L2 row-normalisation is
 // done in registers + one LDS exchange.
 // ---------------------------------------------------------------------------------------------
-#define NGCF_KC 32
+#ifndef NGCF_DC
 #define NGCF_DC 16
+#endif
+#define NGCF_KC (2 * NGCF_DC)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers inside lambdas
@@ -40,8 +42,11 @@ __global__ void pack_weights_kernel(const float *__restrict__ W1, const float *_
         bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
 }
 
+#ifndef NGCF_DENSE_WAVES_PER_EU
+#define NGCF_DENSE_WAVES_PER_EU 1
+#endif
 template <int RW, int CW, int NT, bool ALIGNED, bool FAST>
-__global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restrict__ LE, int64_t ldLE,
+__global__ __launch_bounds__(256, NGCF_DENSE_WAVES_PER_EU) void layer_dense_kernel(const float *__restrict__ LE, int64_t ldLE,
                                                           const float *__restrict__ Es, int64_t ldE, int64_t n_rows,
                                                           int d_in, int d_out, const float *__restrict__ Wt,
                                                           const float *__restrict__ bias2, int n_chunks,
@@ -55,8 +60,11 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
     constexpr int XLD = NGCF_KC + 4;         // 36: rows stay 16-B aligned and b128 column reads are conflict-free
     constexpr bool DB = WCOLS <= 128;        // double-buffered LDS (one barrier per chunk) where two blocks still fit a CU
     constexpr int NBUF = DB ? 2 : 1;
-    constexpr int RR = (BM + 63) / 64;       // X rows staged per thread
-    constexpr int WN = (NGCF_KC * WCOLS / 4) / 256;   // W float4s staged per thread
+    constexpr int SQ = NGCF_DC / 4;          // lanes that cover the input columns of a chunk for one row
+    constexpr int RPP = 256 / SQ;            // rows staged per pass of the workgroup
+    constexpr int RR = (BM + RPP - 1) / RPP; // X rows staged per thread
+    constexpr int WF4 = NGCF_KC * WCOLS / 4;           // float4s of a W chunk
+    constexpr int WN = (WF4 + 255) / 256;              // W float4s staged per thread
     __shared__ float Xs[NBUF * BM * XLD];
     __shared__ float Ws[NBUF * NGCF_KC * WCOLS];
     __shared__ float ssq[BM * CW];
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // staging roles: 4 lanes x 4 columns cover the 16 input columns of a chunk for one row
-    const int sq = tid & 3;
-    const int sr = tid >> 2;   // 0..63
+    const int sq = tid % SQ;
+    const int sr = tid / SQ;   // 0..RPP-1
     f32x4 xle[RR], xe[RR], wreg[WN];
 
     auto load_chunk = [&](int chunk) {       // global -> registers
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
             const bool k0 = c0 < d_in, k1 = c0 + 1 < d_in, k2 = c0 + 2 < d_in, k3 = c0 + 3 < d_in;
 #pragma unroll
             for (int rr = 0; rr < RR; ++rr) {
-                int64_t grow = row0 + (sr + rr * 64) % BM;
+                int64_t grow = row0 + (sr + rr * RPP) % BM;
                 grow = grow < n_rows ? grow : n_rows - 1;
                 f32x4 a = *reinterpret_cast<const f32x4 *>(LE + grow * ldLE + cc);
                 f32x4 b = *reinterpret_cast<const f32x4 *>(Es + grow * ldE + cc);
@@ -100,12 +108,13 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
             }
             const f32x4 *srcw = reinterpret_cast<const f32x4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
 #pragma unroll
-            for (int i = 0; i < WN; ++i) wreg[i] = srcw[tid + i * 256];
+            for (int i = 0; i < WN; ++i)
+                if (WF4 % 256 == 0 || tid + i * 256 < WF4) wreg[i] = srcw[tid + i * 256];
             return;
         }
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) {
-            const int r = sr + rr * 64;
+            const int r = sr + rr * RPP;
             float le[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
             const int64_t grow = row0 + r;
             if (r < BM && grow < n_rows) {
@@ -128,13 +137,14 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
         }
         const f32x4 *src = reinterpret_cast<const f32x4 *>(Wt + (int64_t)chunk * NGCF_KC * WCOLS);
 #pragma unroll
-        for (int i = 0; i < WN; ++i) wreg[i] = src[tid + i * 256];
+        for (int i = 0; i < WN; ++i)
+            if (WF4 % 256 == 0 || tid + i * 256 < WF4) wreg[i] = src[tid + i * 256];
     };
     auto store_chunk = [&](int buf) {        // registers -> LDS: (LE + E) feeds W1, (LE * E) feeds W2
         float *X = Xs + buf * (BM * XLD);
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) {
-            const int r = sr + rr * 64;
+            const int r = sr + rr * RPP;
             if (r < BM) {
                 const f32x4 a = xle[rr], b = xe[rr];
                 *reinterpret_cast<f32x4 *>(X + r * XLD + sq * 4) = a + b;
@@ -143,7 +153,8 @@ __global__ __launch_bounds__(256) void layer_dense_kernel(const float *__restric
         }
         f32x4 *dst = reinterpret_cast<f32x4 *>(Ws + buf * (NGCF_KC * WCOLS));
 #pragma unroll
-        for (int i = 0; i < WN; ++i) dst[tid + i * 256] = wreg[i];
+        for (int i = 0; i < WN; ++i)
+            if (WF4 % 256 == 0 || tid + i * 256 < WF4) dst[tid + i * 256] = wreg[i];
     };
     auto compute_chunk = [&](int buf) {      // 32 k-values: 4 blocks of (one b128 A read, 4 x NT-wide B reads, 4*NT MFMAs)
         const float *X = Xs + buf * (BM * XLD) + (rw * 32 + li) * XLD + lh * 4;
