@@ -5,8 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
 so = os.path.join(ROOT, "tools", "spmm_lab.so")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so,
-                       os.path.join(ROOT, "tools", "spmm_lab.hip")])
+if os.environ.get("NGCF_NO_BUILD") != "1":      # never spawn a compiler under a profiler: build first
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tools", "spmm_lab.hip")])
 lab = C.CDLL(so)
 dev = torch.device("cuda:0")
 U, I, M = 1_000_000, 100_000, 50_000_000
