@@ -551,13 +551,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // DBG: every kDbgEvery chunks a wave stores (s_memrealtime, column it is gathering) into `dbg` - the sweep-spread
 // trace of tools/swept_trace_lab.py (NGCF_SWEPT_TRACE=<file>); the product never runs this instantiation otherwise
 constexpr int kDbgEvery = 2, kDbgSamples = 512;
+// One launch can take up to kMaxLaunchParts parts (row groups) of a product one after the other: a workgroup that has finished
+// its share of the first goes straight on to the second, so the end-of-part stragglers (the last waves finish 5-8 % after the
+// first, profiles/r02_swept_trace.txt) would cost once per product instead of once per part; the sweep steps are numbered
+// through, so the XCD counters need no reset in between.  Off by default (launch_swept: measured slower).
+constexpr int kMaxLaunchParts = 4;
+struct SweptPartArgs {
+    const int64_t *tptr;
+    const int32_t *e_pack;
+    const float *e_val;
+    const int32_t *dst;
+    float *partial;
+    int n_rowpass, n_win, lead;
+};
+struct SweptLaunch {
+    SweptPartArgs part[kMaxLaunchParts];
+    int n_parts;
+};
+
 template <int RW, int NW, bool DBG>
-__global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__restrict__ tptr, const int32_t *__restrict__ e_pack,
-                                                             const float *__restrict__ e_val, const int32_t *__restrict__ dst,
-                                                             int n_rowpass, int n_win, int n_slices, const float *__restrict__ E,
-                                                             int64_t ldE, float *__restrict__ out, int64_t ldo,
-                                                             float *__restrict__ partial, int dp, unsigned *bar, int max_spin, int lead,
-                                                             int sync_k, unsigned prio_cols, int prio_graded, int nt_flags, unsigned long long *__restrict__ dbg)
+__global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int n_slices, const float *__restrict__ E,
+                                                             int64_t ldE, float *__restrict__ out, int64_t ldo, int dp, unsigned *bar,
+                                                             int max_spin, int sync_k, unsigned prio_cols, int prio_graded, int nt_flags,
+                                                             unsigned long long *__restrict__ dbg)
 {
     __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];
@@ -571,24 +587,32 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
     if (threadIdx.x < kRing) wg_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID
-        perm_lds = lead;                        // steps 0..lead wait for nobody
+        perm_lds = L.part[0].lead;              // steps 0..lead wait for nobody
         wg_front = 0;
     }
     __syncthreads();
     unsigned *ctr = bar + xcc_id * 32;
     const unsigned members = gridDim.x / 8;
-    const bool sync = lead >= 0;
-    int perm = lead;                            // this wave's copy of perm_lds
+    int perm = L.part[0].lead;                  // this wave's copy of perm_lds
     int step0 = 0;                              // sweep steps of the passes before this one
     const unsigned ld_bytes = (unsigned)ldE * 4u;
     int dbg_n = 0, dbg_chunk = 0;
     unsigned long long *dbg_w = DBG ? dbg + ((size_t)blockIdx.x * NW + wave) * (2 * kDbgSamples + 2) : nullptr;
     if (DBG && lane == 0) dbg_w[0] = xcc_id;
+    int sweep_no = 0;                           // sweeps (row pass x slice) so far, over all parts
+    for (int pi = 0; pi < L.n_parts; ++pi) {
+    const int64_t *__restrict__ tptr = L.part[pi].tptr;
+    const int32_t *__restrict__ e_pack = L.part[pi].e_pack;
+    const float *__restrict__ e_val = L.part[pi].e_val;
+    const int32_t *__restrict__ dst = L.part[pi].dst;
+    float *__restrict__ partial = L.part[pi].partial;
+    const int n_rowpass = L.part[pi].n_rowpass, n_win = L.part[pi].n_win, lead = L.part[pi].lead;
+    const bool sync = lead >= 0;
     for (int rp = 0; rp < n_rowpass; ++rp) {
         const int64_t task = ((int64_t)rp * gridDim.x + blockIdx.x) * NW + wave;
         const int64_t *tp = tptr + task * n_win;
         const int64_t beg = tp[0], end = tp[n_win];
-        for (int slice = 0; slice < n_slices; ++slice, step0 += (n_win + sync_k - 1) / sync_k) {   // sweep step = sync_k windows
+        for (int slice = 0; slice < n_slices; ++slice, ++sweep_no, step0 += (n_win + sync_k - 1) / sync_k) {   // sweep step = sync_k windows
             const char *Eb = reinterpret_cast<const char *>(E + slice * kSW);   // uniform base + 32-bit lane offsets
             for (int i = lane; i < (RW + 1) * kSW; i += 64) wacc[i] = 0.f;
             int b = 0;
@@ -676,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                 cross(beg, true);
                 offA = (unsigned)(pkA & kColMask) * ld_bytes;
                 NGCF_GATHER_LO(xa)
-                const unsigned sweep_tag = (unsigned)((rp * n_slices + slice) & 0xff) << kRowBits;
+                const unsigned sweep_tag = (unsigned)(sweep_no & 0xff) << kRowBits;
                 for (int64_t pos = beg; pos < end; pos += kCH) {
                     if (prio_cols) {
                         // Inside a workgroup the same few waves fall behind and stay behind (the instruction arbiter serves the
@@ -701,7 +725,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
                     if (DBG) {
                         if (dbg_chunk++ % kDbgEvery == 0 && dbg_n < kDbgSamples && lane == 0) {
                             dbg_w[2 + 2 * dbg_n] = __builtin_amdgcn_s_memrealtime();
-                            dbg_w[3 + 2 * dbg_n] = ((unsigned long long)(rp * n_slices + slice) << 32) | (unsigned)(pkA & kColMask);
+                            dbg_w[3 + 2 * dbg_n] = ((unsigned long long)sweep_no << 32) | (unsigned)(pkA & kColMask);
                             ++dbg_n;
                         }
                     }
@@ -745,6 +769,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(const int64_t *__re
             }
         }
     }
+    }   // parts
     if (DBG && lane == 0) dbg_w[1] = (unsigned long long)dbg_n;
 }
 
@@ -771,22 +796,33 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
     const int prio_graded = env_int("NGCF_SWEPT_PRIO_GRADED", 1);
     const int nt_flags = env_int("NGCF_SWEPT_NT", 0);                          // 1: streaming loads of the entry lists, 2: streaming stores of the rows
     const char *trace = getenv("NGCF_SWEPT_TRACE");
-    int part_no = 0;
-    for (const auto &p : w.parts) {
-        float *pp = partial ? partial + p.partial_base * (int64_t)dp : nullptr;
-        const int lead = std::min(lead_env != -2 ? lead_env : (p.n_win >= 8 ? 2 : 1), kRing - 4);   // sweep steps a wave may run ahead
+    // consecutive parts of the same workgroup shape share a launch
+    // one launch per part by default: taking both halves of C3 in one launch (NGCF_SWEPT_MERGE=1) was measured SLOWER (3.01-3.11
+    // vs 2.96-2.98 ms per product, same box) - the workgroups that start the second part early gather from another table
+    // and take L2 away from the stragglers of the first
+    const int max_parts = getenv("NGCF_SWEPT_MERGE") ? kMaxLaunchParts : 1;
+    for (size_t p0 = 0; p0 < w.parts.size();) {
+        SweptLaunch L{};
+        size_t p1 = p0;
+        for (; p1 < w.parts.size() && L.n_parts < max_parts && w.parts[p1].waves == w.parts[p0].waves; ++p1) {
+            const auto &p = w.parts[p1];
+            // sweep steps a wave may run ahead: by the size of the part's table
+            const int lead = std::min(lead_env != -2 ? lead_env : (p.n_win >= 8 ? 2 : 1), kRing - 4);
+            L.part[L.n_parts++] = SweptPartArgs{p.tptr, p.e_pack, p.e_val, p.dst, partial ? partial + p.partial_base * (int64_t)dp : nullptr,
+                                                p.n_rowpass, p.n_win, lead};
+        }
+        const int waves = w.parts[p0].waves;
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
         unsigned long long *dbg = nullptr;
-        const size_t dbg_words = (size_t)kSweptWGs * p.waves * (2 * kDbgSamples + 2);
+        const size_t dbg_words = (size_t)kSweptWGs * waves * (2 * kDbgSamples + 2);
         if (trace) {
             HIP_TRY(hipMalloc(&dbg, dbg_words * 8));
             HIP_TRY(hipMemsetAsync(dbg, 0, dbg_words * 8, stream));
         }
-#define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_)                                                                                  \
-    spmm_swept_kernel<RW_, NW_, DBG_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(p.tptr, p.e_pack, p.e_val, p.dst, p.n_rowpass, p.n_win, \
-                                                                               d / kSW, E, ldE, out, ldo, pp, dp, w.barrier,   \
-                                                                               max_spin, lead, sync_k, prio_cols, prio_graded, nt_flags, dbg)
-        if (p.waves == 16) {
+#define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_)                                                                                          \
+    spmm_swept_kernel<RW_, NW_, DBG_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, w.barrier, max_spin,  \
+                                                                               sync_k, prio_cols, prio_graded, nt_flags, dbg)
+        if (waves == 16) {
             if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true);
             else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false);
         } else {
@@ -795,13 +831,14 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
         }
 #undef NGCF_SWEPT_LAUNCH
         LAUNCH_CHECK();
-        if (trace) {     // lab only: host-synchronous dump, one file per part (the last launch wins)
+        if (trace) {     // lab only: host-synchronous dump, one file per launch
+            const auto &p = w.parts[p0];
             std::vector<unsigned long long> h(dbg_words);
             HIP_TRY(hipStreamSynchronize(stream));
             HIP_TRY(hipMemcpy(h.data(), dbg, dbg_words * 8, hipMemcpyDeviceToHost));
             (void)hipFree(dbg);
             char path[512];
-            snprintf(path, sizeof(path), "%s.part%d", trace, part_no);
+            snprintf(path, sizeof(path), "%s.part%d", trace, (int)p0);
             if (FILE *f = fopen(path, "wb")) {
                 const long long hdr[6] = {kSweptWGs, p.waves, kDbgSamples, p.win_cols, p.n_win, p.col_lo};
                 fwrite(hdr, sizeof(hdr), 1, f);
@@ -809,7 +846,7 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
                 fclose(f);
             }
         }
-        ++part_no;
+        p0 = p1;
     }
     for (const auto &p : w.parts) {
         if (p.n_heavy == 0) continue;
