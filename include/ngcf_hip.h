@@ -84,7 +84,9 @@ int64_t ngcf_csr_n_rows(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_cols(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_segments(const ngcf_csr_t *csr);
 int64_t ngcf_csr_max_row_len(const ngcf_csr_t *csr);        /* stored entries of the longest row */
-/* rows currently covered by L2-swept parts (0: every product of this CSR runs on the row-wise kernels) */
+/* rows currently covered by L2-swept parts (0: every product of this CSR runs on the row-wise kernels: mode 0/1, a shape the
+ * plan declines - too small, expected re-use below 3, table beyond 32-bit offsets - or a device that does not report 256 CUs,
+ * for which one note is printed on stderr) */
 int64_t ngcf_csr_swept_rows(const ngcf_csr_t *csr);
 /* device pointers of the CSR arrays (for tests / the transposed view) */
 const int64_t *ngcf_csr_rowptr(const ngcf_csr_t *csr);

@@ -472,8 +472,16 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     // other partitioning the grid would not be resident together, so the products stay on the row-wise kernels
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus != kSweptWGs)
+        cus != kSweptWGs) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[ngcf] note: this device reports %d CUs, not %d (an MI355X in SPX mode): the L2-swept SpMM plan is not built and the "
+                            "products run on the row-wise kernels (about half the speed on large graphs); ngcf_csr_swept_rows() returns 0\n",
+                    cus, kSweptWGs);
+        }
         return NGCF_OK;
+    }
     w.group_swept.assign(c->groups.size(), 0);
     for (size_t g = 0; g < c->groups.size(); ++g) {
         ngcf_csr::Swept::Part p;
