@@ -797,3 +797,36 @@ def test_odd_shapes_against_oracle(U, I, inter, d0, layers, B, dev):
     ou, op, on = orc.gather_torch(want, U, batch["u_id"], batch["pos_item"], batch["neg_item"])
     ref_loss = float(orc.bpr_torch(ou, op, on, 0.025, B))
     assert abs(float(loss) - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-6
+
+
+@pytest.mark.parametrize("d_in,d_out,mode", [(128, 128, "eval"), (130, 128, "hash"), (64, 100, "mask"), (144, 128, "last")])
+def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, mode, dev):
+    """layer_dense_resident_kernel (weights resident in LDS, no barriers; taken from 65 536 rows on at 97..128 output columns)
+    against layer_dense_kernel on the same inputs: the k order of every output element is the same, so carry and normalised
+    block must agree bit for bit - in eval mode, with the hash dropout, with a host-drawn noise tensor, and without a carry."""
+    import os
+    eng = _pkg().engine
+    n = 70_001                                               # not a multiple of 32: a partial last tile
+    g = torch.Generator().manual_seed(d_in + d_out)
+    ld = (d_in + 31) // 32 * 32
+    LE = (torch.randn((n, ld), generator=g) * 0.5).to(dev)[:, :d_in]
+    E = (torch.randn((n, ld), generator=g) * 0.5).to(dev)[:, :d_in]
+    W1, W2 = ((torch.randn((d_out, d_in), generator=g) * 0.1).to(dev) for _ in range(2))
+    b1, b2 = ((torch.randn((d_out,), generator=g) * 0.1).to(dev) for _ in range(2))
+    mask = (torch.rand((n, d_out), generator=g) > 0.3).float().to(dev) / 0.7 if mode == "mask" else None
+    kw = dict(drop_p=0.3 if mode in ("hash", "mask") else 0.0, drop_seed=77 if mode == "hash" else 0, drop_mask=mask)
+    outs = []
+    for resident in ("1", "0"):
+        os.environ["NGCF_DENSE_RESIDENT"] = resident
+        carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
+        norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]                # a column slice of a wider matrix
+        eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
+        outs.append((carry, norm.clone()))
+    del os.environ["NGCF_DENSE_RESIDENT"]
+    assert torch.equal(outs[0][1], outs[1][1])
+    if mode != "last":
+        assert torch.equal(outs[0][0], outs[1][0])
+        if mode == "hash":
+            frac = float((outs[0][0] == 0).float().mean())
+            assert abs(frac - 0.3) < 0.01
+    assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
