@@ -360,22 +360,27 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
             ea = *reinterpret_cast<const f32x4 *>(e_row + cca);
             lb = *reinterpret_cast<const f32x4 *>(le_row + ccb);
             eb = *reinterpret_cast<const f32x4 *>(e_row + ccb);
-            if (ca + 4 > d_in) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ca + q >= d_in) la[q] = 0.f, ea[q] = 0.f;
-            }
-            if (cb + 4 > d_in) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (cb + q >= d_in) lb[q] = 0.f, eb[q] = 0.f;
-            }
         };
-        f32x4 la, lb, ea, eb, nla, nlb, nea, neb;
-        fetch(0, la, lb, ea, eb);
-        for (int c = 0; c < n_chunks; ++c) {
-            if (c + 1 < n_chunks) fetch(c + 1, nla, nlb, nea, neb);          // in flight under this chunk's MFMAs
-            const f32x4 a4[4] = {la + ea, lb + eb, la * ea, lb * eb};       // k-blocks: sum cols 0-7, sum 8-15, product 0-7, product 8-15
+        // sums and products of a chunk from its raw pieces; the zeroing of the columns past d_in happens HERE, at use - in
+        // fetch() it would make the loads wait right where they are issued
+        auto form = [&](int c, f32x4 la, f32x4 lb, f32x4 ea, f32x4 eb, f32x4 (&a4)[4]) {
+            const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
+            if (cb + 4 > d_in) {                      // only the last chunk of an odd width
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (ca + q >= d_in) la[q] = 0.f, ea[q] = 0.f;
+                    if (cb + q >= d_in) lb[q] = 0.f, eb[q] = 0.f;
+                }
+            }
+            a4[0] = la + ea, a4[1] = lb + eb, a4[2] = la * ea, a4[3] = lb * eb;   // k-blocks: sum 0-7, sum 8-15, product 0-7, product 8-15
+        };
+        // Two chunks of look-ahead in two fixed register sets (no rotation copies - a copy of a register that is still being
+        // loaded is a wait): the sums and products of a chunk are formed first, which frees its set for the chunk after next.
+        f32x4 la0, lb0, ea0, eb0, la1, lb1, ea1, eb1;
+        fetch(0, la0, lb0, ea0, eb0);
+        la1 = la0, lb1 = lb0, ea1 = ea0, eb1 = eb0;
+        if (n_chunks > 1) fetch(1, la1, lb1, ea1, eb1);
+        auto chunk_mfma = [&](int c, const f32x4 (&a4)[4]) {
             const float *wc = W + (int64_t)c * NGCF_KC * WCOLS;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
@@ -388,7 +393,22 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
                     acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kb][sx], bv.w, acc[3], 0, 0, 0);
                 }
             }
-            la = nla, lb = nlb, ea = nea, eb = neb;
+        };
+        for (int c = 0; c < n_chunks; c += 2) {
+            {
+                f32x4 a4[4];
+                form(c, la0, lb0, ea0, eb0, a4);
+                if (c + 2 < n_chunks) fetch(c + 2, la0, lb0, ea0, eb0);               // in flight under two chunks of MFMAs
+                __builtin_amdgcn_sched_barrier(0);      // (left alone the compiler sinks these loads to just before their use)
+                chunk_mfma(c, a4);
+            }
+            if (c + 1 < n_chunks) {
+                f32x4 a4[4];
+                form(c + 1, la1, lb1, ea1, eb1, a4);
+                if (c + 3 < n_chunks) fetch(c + 3, la1, lb1, ea1, eb1);
+                __builtin_amdgcn_sched_barrier(0);
+                chunk_mfma(c + 1, a4);
+            }
         }
         // ---- epilogue (wave-local): bias, LeakyReLU, dropout, row norm, stores
         const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -397,23 +417,33 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
         const bool any_drop = drop_mask || drop_p > 0.f;
+        if (!any_drop) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = t * 32 + li;
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[t][r] + bz[t];
-                v = v >= 0.f ? v : leaky * v;
-                if (any_drop) {
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t][r] + bz[t];
+                    v = v >= 0.f ? v : leaky * v;
+                    acc[t][r] = v;
+                    rowss[r] = fmaf(v, v, rowss[r]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t][r] + bz[t];
+                    v = v >= 0.f ? v : leaky * v;
                     const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (drop_mask) v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
                     else {
                         const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
                         v = h < drop_thr ? 0.f : v * keep_scale;
                     }
+                    acc[t][r] = v;
+                    rowss[r] = fmaf(v, v, rowss[r]);
                 }
-                acc[t][r] = v;
-                rowss[r] = fmaf(v, v, rowss[r]);
             }
         }
 #pragma unroll
@@ -426,16 +456,34 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
             s2 += __shfl_xor(s2, 16);
             rowss[r] = s2;
         }
-        const bool full = row0 + 32 <= n_rows && d_out == WCOLS;
+        if (row0 + 32 <= n_rows && d_out == WCOLS) {          // full tile: no per-element tests
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float inv = 1.f / fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
+                float *nrow = norm + grow * ldn + li;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) nrow[t * 32] = acc[t][r] * inv;
+            }
+            if (carry) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *crow = carry + (row0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ldc + li;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) crow[t * 32] = acc[t][r];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (!full && grow >= n_rows) continue;
+            if (grow >= n_rows) continue;
             const float inv = 1.f / fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 32 + li;
-                if (full || col < d_out) {
+                if (col < d_out) {
                     const float v = acc[t][r];
                     if (carry) carry[grow * ldc + col] = v;
                     norm[grow * ldn + col] = v * inv;
