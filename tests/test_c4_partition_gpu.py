@@ -1,0 +1,87 @@
+"""BASELINE.json configs[3] (C4: the C3 graph row-partitioned over 8 GPUs with an all-gather of the carry per layer) on the
+one GPU a box has: all EIGHT ranks' slabs are built exactly as `dist.ShardedPropagation.from_interactions` builds them (entry-
+balanced user / item ranges, the user range in 4 row chunks, padded chunk-major / rank-major replica) and run one after the
+other through the real HIP kernels; what the per-chunk RCCL all-gather delivers - every rank's carry rows at its padded positions
+of the next replica - is written there by copies.  The assembled result must be the single-GPU engine's.  (The collective itself is
+covered by the gloo tests of tests/test_dist.py and, with one rank, over RCCL; more than one RCCL rank needs more than one GPU.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c4_eight_rank_partition_simulated_on_one_gpu():
+    import seoul_tourism_recommendation_ngcf_amd as pkg
+    from seoul_tourism_recommendation_ngcf_amd import dist as nd
+    eng = pkg.engine
+    dev = torch.device("cuda:0")
+    U, I, W, C, d = 1_000_000, 100_000, 8, 4, 128
+    u, i, w = pkg.graphs.synthetic_interactions(U, I, 50_000_000, seed=2603, device=dev)
+    coo = pkg.graphs._normalise(u, i, w, U, I)
+    coo.update({"n_user": U, "n_item": I})
+    num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(2603)
+    model = pkg.NGCF(d, [d, d], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 1024, dev).to(dev).eval()
+    with torch.no_grad():
+        want = model.propagate(0).clone()
+    del coo
+    model._csr_cache.clear()
+    torch.cuda.empty_cache()
+
+    v, deg_u, deg_i = nd.laplacian_values(u, i, w, U, I)
+    cnt = torch.cat([deg_u, deg_i]).cpu()
+    ub, ib = nd.balanced_bounds(cnt, 0, U, W), nd.balanced_bounds(cnt, U, U + I, W)
+    lay = nd.ShardLayout(U, I, ub, ib, nd.chunk_bounds(cnt, ub, C))
+    assert lay.chunks == C and lay.P >= U + I
+    ranks = []
+    stored = 0
+    for r in range(W):
+        (ur, uc, uv), (ir, ic, iv) = nd.cut_slabs(u, i, v, U, ub[r], ub[r + 1], ib[r] - U, ib[r + 1] - U)
+        chunks = []
+        for j in range(C):
+            lo, hi = lay.chunk_range(r, j)
+            cr, cc, cv = nd.slab_coo(ur, uc, uv, lo, hi)
+            chunks.append(eng.LaplacianCSR.from_coo(cr, lay.to_padded(cc), cv, hi - lo, lay.P))
+        csr_i = eng.LaplacianCSR.from_coo(ir - ib[r], lay.to_padded(ic), iv, lay.n_items_of(r), lay.P)
+        csr_i.set_mode(3)
+        stored += sum(c.nnz for c in chunks) + csr_i.nnz
+        ranks.append((chunks, csr_i))
+    assert stored == 2 * int(u.numel())                                   # every stored entry of L belongs to exactly one rank
+    per_rank = [sum(c.nnz for c in ch) + ci.nnz for ch, ci in ranks]
+    assert max(per_rank) < 1.03 * min(per_rank)                             # balanced by stored entries
+    del u, i, w, v
+
+    uw, iw = model.user_embedding.weight.detach(), model.item_embedding.weight.detach()
+    w1 = [l.weight.detach() for l in model.w1_list]
+    b1 = [l.bias.detach() for l in model.w1_list]
+    w2 = [l.weight.detach() for l in model.w2_list]
+    b2 = [l.bias.detach() for l in model.w2_list]
+    pos_all = lay.to_padded(torch.arange(U + I, device=dev))
+    full = torch.full((lay.P, d), float("nan"), device=dev)
+    full[pos_all] = torch.cat([uw, iw])
+    full = torch.nan_to_num(full)                                           # padding rows: never referenced
+    got = torch.empty((U + I, 3 * d), device=dev)
+    got[:, :d] = torch.cat([uw, iw])
+    ws = eng.Workspace()
+    for k in range(2):
+        last = k == 1
+        nxt = torch.zeros((lay.P, d), device=dev)
+        off = d * (k + 1)
+        for r, (chunks, csr_i) in enumerate(ranks):
+            ni = lay.n_items_of(r)
+            ipos = lay.item_pos(r)
+            # the rank's item slab; its carry rows land where the item all-gather puts them
+            eng.layer_fused(csr_i, full, full[ipos:ipos + ni], w1[k], b1[k], w2[k], b2[k], None if last else nxt[ipos:ipos + ni],
+                            got[ib[r]:ib[r + 1], off:off + d], ws)
+            for j, csr in enumerate(chunks):                                # user chunks; chunk j's all-gather fills region j
+                lo, hi = lay.chunk_range(r, j)
+                p0 = lay.user_pos(r, j)
+                eng.layer_fused(csr, full, full[p0:p0 + hi - lo], w1[k], b1[k], w2[k], b2[k],
+                                None if last else nxt[p0:p0 + hi - lo], got[lo:hi, off:off + d], ws)
+        full = nxt
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :d], want[:, :d])
+    np.testing.assert_allclose(got[::997].cpu().numpy(), want[::997].cpu().numpy(), atol=2e-5, rtol=2e-3)
+    err = (got - want).abs().max()
+    assert float(err) <= 2e-5 + 2e-3 * float(want.abs().max())
