@@ -1,0 +1,104 @@
+"""Compute time of ONE rank of the row-partitioned C3 graph (BASELINE config 4) at W = 1, 2, 4, 8, on one GPU: the rank's item
+slab and user chunks through the real kernels of dist._propagate_allgather, the exchange left out.  This is the compute side of
+the scaling question only (an upper bound on the speed-up if the all-gather cost nothing); the exchange itself needs more than
+one GPU to measure.  Also prints the bytes a rank receives per layer."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
+from seoul_tourism_recommendation_ngcf_amd import dist as nd  # noqa: E402
+eng = pkg.engine
+dev = torch.device("cuda:0")
+U, I, d, n_layer = 1_000_000, 100_000, 128, 3
+u, i, w = pkg.graphs.synthetic_interactions(U, I, 50_000_000, seed=2603, device=dev)
+v, deg_u, deg_i = nd.laplacian_values(u, i, w, U, I)
+cnt = torch.cat([deg_u, deg_i]).cpu()
+g = torch.Generator().manual_seed(1)
+W1, W2 = ((torch.rand((d, d), generator=g) - 0.5).to(dev) * 0.2 for _ in range(2))
+b1, b2 = ((torch.rand((d,), generator=g) - 0.5).to(dev) * 0.1 for _ in range(2))
+ws = eng.Workspace()
+base = None
+SWEPT_CHUNKS = os.environ.get("LAB_SWEPT_CHUNKS") == "1"      # plan the user chunks for the swept kernel too (mode 3)
+for W in (1, 2, 4, 8):
+    C = int(os.environ.get("LAB_CHUNKS", "4")) if W > 1 else 1
+    ub, ib = nd.balanced_bounds(cnt, 0, U, W), nd.balanced_bounds(cnt, U, U + I, W)
+    lay = nd.ShardLayout(U, I, ub, ib, nd.chunk_bounds(cnt, ub, C))
+    r = W // 2
+    (ur, uc, uv), (ir, ic, iv) = nd.cut_slabs(u, i, v, U, ub[r], ub[r + 1], ib[r] - U, ib[r + 1] - U)
+    chunks = []
+    for j in range(C):
+        lo, hi = lay.chunk_range(r, j)
+        cr, cc, cv = nd.slab_coo(ur, uc, uv, lo, hi)
+        c = eng.LaplacianCSR.from_coo(cr, lay.to_padded(cc), cv, hi - lo, lay.P)
+        if W == 1 or SWEPT_CHUNKS:
+            c.set_mode(3)
+        chunks.append(c)
+    csr_i = eng.LaplacianCSR.from_coo(ir - ib[r], lay.to_padded(ic), iv, lay.n_items_of(r), lay.P)
+    csr_i.set_mode(3)
+    full = torch.randn((lay.P, d), device=dev) * 0.1
+    nxt = torch.empty((lay.P, d), device=dev)
+    out_u = torch.empty((lay.n_users_of(r), d), device=dev)
+    out_i = torch.empty((lay.n_items_of(r), d), device=dev)
+
+    def layer():
+        ip = lay.item_pos(r)
+        eng.layer_fused(csr_i, full, full[ip:ip + lay.n_items_of(r)], W1, b1, W2, b2, nxt[ip:ip + lay.n_items_of(r)], out_i, ws)
+        for j, c in enumerate(chunks):
+            lo, hi = lay.chunk_range(r, j)
+            p0 = lay.user_pos(r, j)
+            eng.layer_fused(c, full, full[p0:p0 + hi - lo], W1, b1, W2, b2, nxt[p0:p0 + hi - lo], out_u[lo - ub[r]:hi - ub[r]], ws)
+    for _ in range(3):
+        layer()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        layer()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    base = base or ms
+    recv = (W - 1) / W * (U + I) * d * 4
+    print(f"W={W}: rank {r} holds {sum(c.nnz for c in chunks) + csr_i.nnz} stored entries, swept rows {[csr_i.swept_rows] + [c.swept_rows for c in chunks]}; "
+          f"compute {ms:.3f} ms per layer ({n_layer * ms:.2f} ms per 3-layer step, {base / ms:.2f}x the W=1 rank); "
+          f"all-gather: {recv / 1e6:.0f} MB received per rank and layer = {recv / 153e9 * 1e3 / max(W - 1, 1) * (W - 1) / 7 if W > 1 else 0:.2f} ms if all 7 links "
+          f"of 153 GB/s were busy, {recv / 153e9 * 1e3:.2f} ms over one link", flush=True)
+
+# ---- the bipartite scheme: users partitioned, items replicated; per rank: item partial sums over the local users (small table,
+# high re-use), the local user rows (gather from the replicated item block), the dense half for the local users and for ALL items
+print("bipartite scheme, one rank's compute (the [I, d] all-reduce of 51 MB per layer left out):", flush=True)
+base = None
+for W in (1, 2, 4, 8):
+    eb = nd.even_bounds(0, U, W)
+    r = W // 2
+    lo, hi = eb[r], eb[r + 1]
+    (ur, uc, uv), _ = nd.cut_slabs(u, i, v, U, lo, hi, 0, 0)
+    csr_u = eng.LaplacianCSR.from_coo(ur - lo, uc - U, uv, hi - lo, I)
+    order = torch.sort(uc, stable=True).indices
+    csr_it = eng.LaplacianCSR.from_coo(uc[order] - U, ur[order] - lo, uv[order], I, hi - lo)
+    csr_it.set_mode(3)
+    csr_u.set_mode(3 if (W == 1 or os.environ.get("LAB_SWEPT_CHUNKS") == "1") else 0)
+    eu = torch.randn((hi - lo, d), device=dev) * 0.1
+    ei = torch.randn((I, d), device=dev) * 0.1
+    part = torch.empty((I, d), device=dev)
+    cu, nu_ = torch.empty((hi - lo, d), device=dev), torch.empty((hi - lo, d), device=dev)
+    ci, ni_ = torch.empty((I, d), device=dev), torch.empty((I, d), device=dev)
+
+    def layer_b():
+        eng.spmm(csr_it, eu, out=part, ws=ws)
+        eng.layer_fused(csr_u, ei, eu, W1, b1, W2, b2, cu, nu_, ws)
+        eng.layer_dense(part, ei, W1, b1, W2, b2, ci, ni_, ws)
+    for _ in range(3):
+        layer_b()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        layer_b()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    base = base or ms
+    print(f"W={W}: rank {r}: {csr_u.nnz + csr_it.nnz} stored entries, swept rows [{csr_it.swept_rows}, {csr_u.swept_rows}]; compute {ms:.3f} ms per layer "
+          f"({n_layer * ms:.2f} ms per step, {base / ms:.2f}x the W=1 rank)", flush=True)
