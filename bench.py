@@ -224,6 +224,8 @@ def main():
 
     if full_forward:
         csr = model.laplacian_csr(0)
+        if args.seg_len:
+            csr.plan(args.seg_len)
         local_nnz = csr.nnz
         spmm_shapes = [(csr.nnz, csr.n_rows, csr.n_cols)]
         feats = {k: torch.randint(0, c, (args.batch,), generator=g).to(dev)

@@ -68,7 +68,9 @@ int ngcf_csr_from_coo(const int64_t *rows, const int64_t *cols, const float *val
 int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx, const float *vals,
                          int64_t n_rows, int64_t n_cols, int64_t nnz, ngcf_csr_t **out, void *stream);
 /* Re-plan the row segmentation: rows with more than `seg_len` stored entries are cut into
- * segments of `seg_len` entries whose partial sums are combined in a fixed order (no atomics). */
+ * segments of `seg_len` entries whose partial sums are combined in a fixed order (no atomics).
+ * The constructors plan with a default that grows with the matrix: the power of two in [64, 2048]
+ * that gives about 4 096 segments or more (2048 from 4 M stored entries up). */
 int ngcf_csr_plan(ngcf_csr_t *csr, int32_t seg_len, void *stream);
 /* SpMM kernel choice.  0 = row-wise gather kernels, d-sliced on the row groups whose gathered table is small
  * (default: right for matrices that live for one product, e.g. the per-layer node-dropout matrices); 1 = row-wise

@@ -80,7 +80,12 @@ struct ngcf_csr {
     int32_t *heavy_row = nullptr;      // device [n_heavy] rows that were cut
     int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1] their segment ranges
     // row groups: maximal runs of rows whose gathered column range is small enough that d-slicing pays
-    struct RowGroup { int64_t begin, end; bool sliceable; int32_t col_lo, col_hi; };   // col_hi < col_lo: no entries
+    struct RowGroup {                   // col_hi < col_lo: no entries
+        int64_t begin, end;
+        bool sliceable;
+        int32_t col_lo, col_hi;
+        bool lds_table = false;        // the rows gather from <= kLdsTableRows table rows: spmm_ldstab_kernel
+    };
     std::vector<RowGroup> groups;
     // L2-swept plan (spmm_swept.hip): built on request (mode 2/3) for long-lived matrices
     int mode = 0;                      // 0 row-wise (+ d-sliced groups), 1 row-wise only, 2 swept wherever the shape
@@ -115,7 +120,18 @@ struct ngcf_csr {
 };
 
 
+static const int32_t kLdsTableRows = 512;      // x 256 B (one 64-float slice) = 128 KiB of LDS
 static const int32_t kDefaultSegLen = 2048;   // measured on C3: 512 -> 20.9 ms/step, 2048 -> 20.6, 4096 -> 20.5
+// Default segment length of a matrix with `nnz` stored entries.  A wave walks its segment 8 gathers at a time, so a small matrix
+// with a few very long rows (the Seoul graph: 100 item rows of ~4 400 entries) is latency-bound on a few hundred waves at 2048;
+// aim at >= 4 096 segments instead.  Seoul-shaped C2 / C1 (876 K entries, whole forward as a hipGraph): 2048 -> 0.967 / 0.232 ms,
+// 512 -> 0.607 / 0.145, 256 -> 0.577 / 0.139, 128 -> 0.621 / 0.149, 64 -> 0.652 / 0.169.
+static inline int32_t default_seg_len(int64_t nnz)
+{
+    int32_t s = 64;
+    while (s < kDefaultSegLen && (int64_t)s * 4096 < nnz) s *= 2;
+    return s;
+}
 
 void free_swept(ngcf_csr *c);                                  // spmm_swept.hip
 int build_swept_plan(ngcf_csr *c, hipStream_t stream);         // spmm_swept.hip (reads c->mode)
@@ -153,6 +169,16 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// value of lane U of this lane's 16-lane row (DPP row_newbcast: one VALU op, no LDS round trip)
+template <int U> __device__ inline int row_bcast(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false);
+}
+template <int U> __device__ inline float row_bcast(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + U, 0xf, 0xf, false));
+}
+
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using type = float4; };
 template <> struct VecT<2> { using type = float2; };

@@ -103,10 +103,9 @@ __global__ void coo_copy_kernel(const int64_t *__restrict__ cols, const float *_
 }
 
 
-// per 1024-row block: smallest and largest column any of its rows gathers (one-time, plan only)
-#define NGCF_GROUP_ROWS 1024
+// per block of `group_rows` rows: smallest and largest column any of its rows gathers (one-time, plan only)
 __global__ void row_colrange_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
-                                    int64_t n_rows, int32_t *__restrict__ blk_min, int32_t *__restrict__ blk_max)
+                                    int64_t n_rows, int group_rows, int32_t *__restrict__ blk_min, int32_t *__restrict__ blk_max)
 {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
@@ -117,8 +116,8 @@ __global__ void row_colrange_kernel(const int64_t *__restrict__ rowptr, const in
         hi = c > hi ? c : hi;
     }
     if (hi >= 0) {
-        atomicMin(&blk_min[row / NGCF_GROUP_ROWS], lo);
-        atomicMax(&blk_max[row / NGCF_GROUP_ROWS], hi);
+        atomicMin(&blk_min[row / group_rows], lo);
+        atomicMax(&blk_max[row / group_rows], hi);
     }
 }
 
@@ -136,6 +135,9 @@ static int build_row_groups(ngcf_csr *c, hipStream_t stream)
 {
     c->groups.clear();
     if (c->n_rows == 0) return NGCF_OK;
+    // blocks of 1024 rows; 64 on a small matrix, where the border between the user rows and the item rows of a Seoul-sized
+    // graph (5 840 + 100 rows) would otherwise put an eighth of the user rows into a mixed block
+    const int64_t NGCF_GROUP_ROWS = c->n_rows <= 65536 ? 64 : 1024;
     const int64_t nb = (c->n_rows + NGCF_GROUP_ROWS - 1) / NGCF_GROUP_ROWS;
     int32_t *d_min = nullptr, *d_max = nullptr;
     std::vector<int32_t> h_min((size_t)nb), h_max((size_t)nb);
@@ -144,7 +146,7 @@ static int build_row_groups(ngcf_csr *c, hipStream_t stream)
         HIP_TRY(hipMalloc(&d_max, sizeof(int32_t) * (size_t)nb));
         HIP_TRY(hipMemsetAsync(d_min, 0x7f, sizeof(int32_t) * (size_t)nb, stream));   // 0x7f7f7f7f: large
         HIP_TRY(hipMemsetAsync(d_max, 0xff, sizeof(int32_t) * (size_t)nb, stream));   // -1
-        row_colrange_kernel<<<(int)((c->n_rows + 255) / 256), 256, 0, stream>>>(c->rowptr, c->colidx, c->n_rows, d_min, d_max);
+        row_colrange_kernel<<<(int)((c->n_rows + 255) / 256), 256, 0, stream>>>(c->rowptr, c->colidx, c->n_rows, (int)NGCF_GROUP_ROWS, d_min, d_max);
         LAUNCH_CHECK();
         HIP_TRY(hipMemcpyAsync(h_min.data(), d_min, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(h_max.data(), d_max, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, stream));
@@ -155,20 +157,44 @@ static int build_row_groups(ngcf_csr *c, hipStream_t stream)
     if (d_min) (void)hipFree(d_min);
     if (d_max) (void)hipFree(d_max);
     if (rc != NGCF_OK) return rc;
+    // class of a row block: 2 = its rows gather from at most kLdsTableRows table rows (the user rows of a graph with a
+    // few hundred items - the Seoul data has ~100: the table slice is staged in LDS), 1 = sliceable, 0 = neither
+    auto block_class = [&](int64_t b) {
+        if (h_max[(size_t)b] < 0) return 1;
+        const int64_t range = (int64_t)h_max[(size_t)b] - h_min[(size_t)b] + 1;
+        return range <= kLdsTableRows ? 2 : range <= kSliceFootprintRows ? 1 : 0;
+    };
+    std::vector<int> cls;
     for (int64_t b = 0; b < nb; ++b) {
-        const bool s = h_max[(size_t)b] < 0 || (int64_t)h_max[(size_t)b] - h_min[(size_t)b] + 1 <= kSliceFootprintRows;
+        const int k = block_class(b);
         const int64_t lo = b * NGCF_GROUP_ROWS, hi = std::min<int64_t>(c->n_rows, lo + NGCF_GROUP_ROWS);
-        if (!c->groups.empty() && c->groups.back().sliceable == s)
+        if (!c->groups.empty() && cls.back() == k) {
             c->groups.back().end = hi;
-        else
-            c->groups.push_back({lo, hi, s, INT32_MAX, -1});
+        } else {
+            c->groups.push_back({lo, hi, k >= 1, INT32_MAX, -1, k == 2});
+            cls.push_back(k);
+        }
+    }
+    // an LDS-table group must gather from ONE small range as a whole, not only block by block
+    for (size_t i = 0; i < c->groups.size(); ++i) {
+        if (!c->groups[i].lds_table) continue;
+        int32_t lo = INT32_MAX, hi = -1;
+        for (int64_t b = c->groups[i].begin / NGCF_GROUP_ROWS; b * NGCF_GROUP_ROWS < c->groups[i].end; ++b)
+            if (h_max[(size_t)b] >= 0) lo = std::min(lo, h_min[(size_t)b]), hi = std::max(hi, h_max[(size_t)b]);
+        if (hi >= 0 && (int64_t)hi - lo + 1 > kLdsTableRows) c->groups[i].lds_table = false;
     }
     // a group of a few blocks is not worth its own launch: give it its neighbour's class, then fuse equal neighbours
-    for (size_t i = 0; i < c->groups.size(); ++i)
-        if (c->groups.size() > 1 && c->groups[i].end - c->groups[i].begin < 16 * NGCF_GROUP_ROWS)
-            c->groups[i].sliceable = c->groups[i > 0 ? i - 1 : i + 1].sliceable;
+    // (LDS-table groups keep to themselves: on a Seoul-shaped graph they are most of the rows of a six-block matrix)
+    auto same = [&](size_t a, size_t b) {
+        return c->groups[a].sliceable == c->groups[b].sliceable && !c->groups[a].lds_table && !c->groups[b].lds_table;
+    };
+    for (size_t i = 0; i < c->groups.size(); ++i) {
+        if (c->groups[i].lds_table || c->groups.size() == 1 || c->groups[i].end - c->groups[i].begin >= 16 * NGCF_GROUP_ROWS) continue;
+        const size_t nb_i = i > 0 ? i - 1 : i + 1;
+        if (!c->groups[nb_i].lds_table) c->groups[i].sliceable = c->groups[nb_i].sliceable;
+    }
     for (size_t k = 1; k < c->groups.size();) {
-        if (c->groups[k].sliceable == c->groups[k - 1].sliceable) {
+        if (same(k, k - 1)) {
             c->groups[k - 1].end = c->groups[k].end;
             c->groups.erase(c->groups.begin() + (long)k);
         } else {
@@ -263,7 +289,7 @@ extern "C" int ngcf_csr_from_arrays(const int64_t *rowptr, const int32_t *colidx
     c->colidx = const_cast<int32_t *>(colidx);
     c->vals = const_cast<float *>(vals);
     c->owns = false;
-    const int rc = ngcf_csr_plan(c, kDefaultSegLen, stream);
+    const int rc = ngcf_csr_plan(c, default_seg_len(c->nnz), stream);
     if (rc != NGCF_OK) {
         ngcf_csr_free(c);
         return rc;
@@ -338,7 +364,7 @@ extern "C" int ngcf_csr_from_coo(const int64_t *rows, const int64_t *cols, const
             HIP_TRY(hipMemcpyAsync(c->vals, ov.data(), sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
-        return ngcf_csr_plan(c, kDefaultSegLen, stream);
+        return ngcf_csr_plan(c, default_seg_len(c->nnz), stream);
     };
     rc = body();
     if (flags) (void)hipFree(flags);

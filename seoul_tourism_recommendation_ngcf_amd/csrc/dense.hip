@@ -21,25 +21,35 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers inside lambdas
 
-__global__ void pack_weights_kernel(const float *__restrict__ W1, const float *__restrict__ b1,
-                                    const float *__restrict__ W2, const float *__restrict__ b2, int d_in, int d_out,
-                                    int n_chunks, int DOP, int NT, float *__restrict__ Wt, float *__restrict__ bias2)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ W1, const float *__restrict__ b1,
+                                                           const float *__restrict__ W2, const float *__restrict__ b2, int d_in,
+                                                           int d_out, int n_chunks, int DOP, int NT, float *__restrict__ Wt,
+                                                           float *__restrict__ bias2)
 {
-    // Wt[chunk][kl][cw][j][t] = weight of output column (cw*NT + t)*32 + j: a lane reads its NT tile values at once
-    const int total = n_chunks * NGCF_KC * DOP;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int within = i % DOP;
+    // Wt[chunk][kl][cw][j][t] = weight of output column (cw*NT + t)*32 + j: a lane reads its NT tile values at once.
+    // One workgroup per (chunk, 32 packed columns): the 16 input columns of the chunk are read along the rows of W1 / W2
+    // (64-byte runs), turned in LDS, and leave as 128-byte runs of the packed row.
+    __shared__ float tile[NGCF_KC][33];
+    const int groups = DOP / 32;
+    const int chunk = blockIdx.x / groups, g = blockIdx.x % groups;
+    for (int idx = threadIdx.x; idx < 32 * NGCF_KC; idx += 256) {
+        const int w = idx / NGCF_KC, kl = idx % NGCF_KC;
+        const int within = g * 32 + w;
         const int t = within % NT, j = (within / NT) % 32, cw = within / (NT * 32);
         const int oc = (cw * NT + t) * 32 + j;
-        const int k = i / DOP;
-        const int chunk = k / NGCF_KC, kl = k % NGCF_KC;
         const int col = chunk * NGCF_DC + (kl % NGCF_DC);
-        float w = 0.f;
-        if (oc < d_out && col < d_in) w = (kl < NGCF_DC ? W1 : W2)[(int64_t)oc * d_in + col];
-        Wt[i] = w;
+        float v = 0.f;
+        if (oc < d_out && col < d_in) v = (kl < NGCF_DC ? W1 : W2)[(int64_t)oc * d_in + col];
+        tile[kl][w] = v;
     }
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < DOP; j += gridDim.x * blockDim.x)
-        bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * NGCF_KC; idx += 256) {
+        const int kl = idx / 32, w = idx % 32;
+        Wt[((int64_t)chunk * NGCF_KC + kl) * DOP + g * 32 + w] = tile[kl][w];
+    }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < DOP; j += 256)
+            bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
 }
 
 #ifndef NGCF_DENSE_WAVES_PER_EU
@@ -187,12 +197,20 @@ __global__ __launch_bounds__(256, NGCF_DENSE_WAVES_PER_EU) void layer_dense_kern
             __syncthreads();
         }
     } else {
+        // one LDS buffer (256 / 512 output columns: a chunk of W is 32 / 64 KB): the next chunk waits in registers while this
+        // one is multiplied, so the global loads are hidden and only the LDS stores sit between the two barriers
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            load_chunk(chunk);
-            store_chunk(0);
-            __syncthreads();
+            const bool more = chunk + 1 < n_chunks;
+            if (more) load_chunk(chunk + 1);
             compute_chunk(0);
             __syncthreads();
+            if (more) {
+                store_chunk(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -553,7 +571,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const int n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
     float *Wt = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
     float *bias2 = Wt + (int64_t)n_chunks * NGCF_KC * dop;
-    pack_weights_kernel<<<64, 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, dop <= 128 ? dop / 32 : 4, Wt, bias2);
+    pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, dop <= 128 ? dop / 32 : 4, Wt, bias2);
     LAUNCH_CHECK();
     const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
 #define NGCF_DENSE(RW, CW, NT) \

@@ -63,6 +63,140 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
 }
 
 
+// Rows that gather from a table of at most kLdsTableRows rows (a graph with a few hundred items: the user rows of the Seoul
+// data gather from ~100 item rows): the 64-float slice of the whole table is staged in LDS once per workgroup and every
+// gather is a ds_read_b128 - 128 B/clk per CU instead of the ~33 B/clk a CU gets from L2 for gathers that miss its L1.
+// Grid (row blocks, slices); 8 waves share one copy of the table slice (three workgroups per CU at ~70 registers), a wave takes
+// every 8th row of its workgroup's block.
+constexpr int kLdsTabWaves = 8;
+template <int U>
+__global__ __launch_bounds__(kLdsTabWaves * 64) void spmm_ldstab_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                          const float *__restrict__ vals, int64_t row_begin, int64_t row_end,
+                                                          int rows_per_wg, int seg_len, const float *__restrict__ E, int64_t ldE,
+                                                          int d, int col_lo, int n_tab, float *__restrict__ out, int64_t ldo,
+                                                          EdgeDrop dr)
+{
+    extern __shared__ float4 tab4[];               // [n_tab + 1][16]: one 64-float slice of table rows col_lo .. col_lo + n_tab - 1, then a row of zeros
+    const int slice = blockIdx.y;
+    const int w = d - slice * 64 < 64 ? d - slice * 64 : 64;      // width of this slice (a multiple of 4)
+    for (int i = threadIdx.x; i < (n_tab + 1) * 16; i += kLdsTabWaves * 64) {
+        const int r = i >> 4, q = i & 15;
+        float4 v = vzero4();
+        if (q * 4 < w && r < n_tab) v = *reinterpret_cast<const float4 *>(E + (int64_t)(col_lo + r) * ldE + slice * 64 + q * 4);
+        tab4[i] = v;
+    }
+    __syncthreads();
+    const float *tab = reinterpret_cast<const float *>(tab4) - (int64_t)col_lo * 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r0 = row_begin + (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = r0 + rows_per_wg < row_end ? r0 + rows_per_wg : row_end;
+    // this wave's rows r0 + wave + 8 k, k < K <= 64: lane k reads the bounds of row k (one round trip for all of them)
+    const int K = r0 + wave < r1 ? (int)((r1 - r0 - wave + kLdsTabWaves - 1) / kLdsTabWaves) : 0;
+    long long rb = 0, re = 0;
+    if (lane < K) {
+        const int64_t row = r0 + wave + (int64_t)lane * kLdsTabWaves;
+        rb = rowptr[row];
+        re = rowptr[row + 1];
+    }
+    auto bcast64 = [](long long x, int k) {       // lane k's 64-bit value as two 32-bit shuffles (the library's 64-bit __shfl goes through the stack)
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)(x & 0xffffffffll), k), hi = (unsigned)__shfl((int)(x >> 32), k);
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    auto store = [&](int k, const float4 &res) {
+        if (lane < 16 && lane * 4 < w)
+            *reinterpret_cast<float4 *>(out + (r0 + wave + (int64_t)k * kLdsTabWaves) * ldo + slice * 64 + lane * 4) = res;
+    };
+    if (dr.n > 0) {        // edge dropout: the general walk (hash + in-wave compaction per batch of 64 entries)
+        for (int k = 0; k < K; ++k) {
+            const int64_t begin = bcast64(rb, k), end = bcast64(re, k);
+            if (end - begin > seg_len) continue;       // cut row: produced from its segments
+            float4 acc[1];
+            acc[0] = vzero4();
+            spmm_accumulate<4, 16, 1, U>(colidx, vals, begin, end, tab, 64, 64, acc, dr, col_lo);
+            store(k, acc[0]);
+        }
+        return;
+    }
+    // Without dropout the walk is pipelined: the first 128 entries of row k+1 are requested before row k is multiplied, in two
+    // fixed register sets (a copy of a register that is still being loaded would be a wait), so a wave pays the memory round
+    // trip once, not once per row and batch.  Inside a batch of 64 entries lane (g, p) holds entry 4 p + g, so the four entries
+    // of round u sit in lane u of the four 16-lane rows and reach their row with DPP broadcasts (the shuffles of the general
+    // walk are LDS instructions and would compete with the table reads); slots past the end point at the zero row.
+    const int g = lane >> 4, pl = lane & 15;
+    const int held = pl * 4 + g;
+    const char *tab_lane = reinterpret_cast<const char *>(tab4) + pl * 16;
+    const int zero_off = n_tab * 256;
+    struct Batch {
+        int c0, c1, n;
+        float v0, v1;
+        int64_t begin;
+    };
+    auto fetch = [&](int k, Batch &t) {
+        t.begin = bcast64(rb, k);
+        const int64_t len = bcast64(re, k) - t.begin;
+        t.n = __builtin_amdgcn_readfirstlane(len > seg_len ? -1 : (int)len);   // -1: cut row, produced from its segments
+        t.c0 = t.c1 = col_lo;
+        t.v0 = t.v1 = 0.f;
+        if (held < t.n) {
+            t.c0 = colidx[t.begin + held];
+            t.v0 = vals[t.begin + held];
+        }
+        if (held + 64 < t.n) {
+            t.c1 = colidx[t.begin + 64 + held];
+            t.v1 = vals[t.begin + 64 + held];
+        }
+    };
+    // one batch: `cnt` entries (1..64), this lane's at index `held`
+    auto consume = [&](int c, float v, int cnt, float4 &acc) {
+        cnt = __builtin_amdgcn_readfirstlane(cnt);         // the same in every lane: let the compiler know
+        const int off = held < cnt ? (c - col_lo) * 256 : zero_off;
+        v = held < cnt ? v : 0.f;
+        // four rounds (16 entries) per step: the four table reads are issued together; the step condition is wave-uniform
+#define NGCF_TAB_QUAD(u0, u1, u2, u3)                                                                   \
+    if (4 * u0 < cnt) {                                                                                 \
+        const float4 x0 = *reinterpret_cast<const float4 *>(tab_lane + row_bcast<u0>(off));            \
+        const float4 x1 = *reinterpret_cast<const float4 *>(tab_lane + row_bcast<u1>(off));            \
+        const float4 x2 = *reinterpret_cast<const float4 *>(tab_lane + row_bcast<u2>(off));            \
+        const float4 x3 = *reinterpret_cast<const float4 *>(tab_lane + row_bcast<u3>(off));            \
+        acc = vfma(row_bcast<u0>(v), x0, acc);                                                          \
+        acc = vfma(row_bcast<u1>(v), x1, acc);                                                          \
+        acc = vfma(row_bcast<u2>(v), x2, acc);                                                          \
+        acc = vfma(row_bcast<u3>(v), x3, acc);                                                          \
+    }
+        NGCF_TAB_QUAD(0, 1, 2, 3) NGCF_TAB_QUAD(4, 5, 6, 7) NGCF_TAB_QUAD(8, 9, 10, 11) NGCF_TAB_QUAD(12, 13, 14, 15)
+#undef NGCF_TAB_QUAD
+    };
+    auto multiply = [&](int k, const Batch &t) {
+        if (t.n < 0) return;
+        float4 acc[1];
+        acc[0] = vzero4();
+        if (t.n > 0) consume(t.c0, t.v0, t.n < 64 ? t.n : 64, acc[0]);
+        if (t.n > 64) consume(t.c1, t.v1, t.n < 128 ? t.n - 64 : 64, acc[0]);
+        for (int done = 128; done < t.n; done += 64) {     // rows of more than 128 entries: the rest batch by batch
+            const int cnt = t.n - done < 64 ? t.n - done : 64;
+            int c = col_lo;
+            float v = 0.f;
+            if (held < cnt) {
+                c = colidx[t.begin + done + held];
+                v = vals[t.begin + done + held];
+            }
+            consume(c, v, cnt, acc[0]);
+        }
+        spmm_combine<4, 16, 1>(acc);
+        store(k, acc[0]);
+    };
+    Batch A, B;
+    if (K > 0) fetch(0, A);
+    for (int k = 0; k < K; k += 2) {
+        if (k + 1 < K) fetch(k + 1, B);
+        multiply(k, A);
+        if (k + 1 < K) {
+            if (k + 2 < K) fetch(k + 2, A);
+            multiply(k + 1, B);
+        }
+    }
+}
+
 // Compact side table of a 1..4-column tail panel: T[c] = {E[c, 0..tail), 0...} as one 16-byte row per table row.  The widths
 // the reference forces on the first layer (65, 130, 515: NGCF.py:39-43) leave 1..3 columns beyond the wide panel; gathered
 // from the strided table each of them costs a 64-byte sector per stored entry (100 M isolated sectors on C3, ~2 ms), from
@@ -233,11 +367,34 @@ int launch_spmm(const SpmmArgs &a)
     const int64_t seg_blocks = (n_seg + 3) / 4;
     // d-slicing of the sliceable row groups needs 16-byte slices of 32 floats
     const bool can_slice = VEC == 4 && a.d % 32 == 0 && a.d >= 64 && c->mode != 1 && !getenv("NGCF_NO_SLICING");
+    // table-in-LDS kernel for the groups that gather from a few hundred rows: 16-byte pieces of 64-float slices
+    const bool can_ldstab = VEC == 4 && a.d % 4 == 0 && c->mode != 1 && !getenv("NGCF_NO_LDSTAB");
     bool seg_done = seg_blocks == 0;
     for (size_t g = 0; g <= c->groups.size(); ++g) {
         const bool last = g == c->groups.size();
         if (last && seg_done) break;
         if (!last && a.with_swept && c->swept.group_swept[g]) continue;
+        if (!last && can_ldstab && c->groups[g].lds_table && c->groups[g].col_hi >= c->groups[g].col_lo) {
+            const auto &grp = c->groups[g];
+            const int64_t n_rows_g = grp.end - grp.begin;
+            const int n_tab = grp.col_hi - grp.col_lo + 1, n_slices = (a.d + 63) / 64;
+            // rows per workgroup: three workgroups per CU when the group is large enough, at least one row per wave
+            int64_t rpw = (n_rows_g * n_slices + 767) / 768;
+            rpw = std::min<int64_t>(std::max<int64_t>((rpw + kLdsTabWaves - 1) / kLdsTabWaves * kLdsTabWaves, kLdsTabWaves), 64 * kLdsTabWaves);
+            const int64_t rb = (n_rows_g + rpw - 1) / rpw;
+            const size_t lds = ((size_t)n_tab + 1) * 256;
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_ldstab_kernel<4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsTableRows + 1) * 256));
+                attr_set = true;
+            }
+            spmm_ldstab_kernel<4><<<dim3((unsigned)rb, (unsigned)n_slices), kLdsTabWaves * 64, lds, a.stream>>>(
+                c->rowptr, c->colidx, c->vals, grp.begin, grp.end, (int)rpw, c->seg_len, a.E, a.ldE, a.d, grp.col_lo, n_tab, a.out,
+                a.ldo, a.dr);
+            LAUNCH_CHECK();
+            continue;
+        }
         if (!last && can_slice && c->groups[g].sliceable) {
             const int64_t rb = (c->groups[g].end - c->groups[g].begin + 3) / 4;
             const int64_t blocks = rb * (a.d / 32);

@@ -14,15 +14,71 @@
 // private partial sums that are combined with DPP/bpermute shuffles at the end.
 // VEC = 1 is the any-width / any-alignment form (Seoul's d = 65).
 // ---------------------------------------------------------------------------------------------
+// The entries a wave holds in registers - lane i has the i-th (column, value) pair, `cnt` of them - are walked G = 64/LPR at a
+// time, U wave instructions in flight; `coff[ch]` is the column offset of the lane's ch-th piece of a gathered row.
 template <int VEC, int LPR, int CH, int U>
-__device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
-                                       int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
-                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr})
+__device__ inline void spmm_consume(int c, float v, int cnt, const float *__restrict__ E, int64_t ldE, const int (&coff)[CH],
+                                    typename VecT<VEC>::type (&acc)[CH])
 {
     using V = typename VecT<VEC>::type;
     constexpr int G = 64 / LPR;
+    const int g = (threadIdx.x & 63) / LPR;
+    int j = 0;
+    for (; j + G * U <= cnt; j += G * U) {          // full batches: every slot is a real entry
+        V x[U][CH];
+        float vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = j + u * G + g;
+            const int cc = __shfl(c, idx);
+            vv[u] = __shfl(v, idx);
+            const float *src = E + (int64_t)cc * ldE;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) acc[ch] = vfma(vv[u], x[u][ch], acc[ch]);
+    }
+    if (j < cnt) {                                   // tail batch: slots past cnt are masked
+        V x[U][CH];
+        float vv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = j + u * G + g;
+            ok[u] = idx < cnt;
+            const int cc = __shfl(c, idx & 63);
+            vv[u] = __shfl(v, idx & 63);
+            const float *src = E + (int64_t)cc * ldE;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) acc[ch] = vsel(ok[u], vfma(vv[u], x[u][ch], acc[ch]), acc[ch]);
+    }
+}
+
+// the G lane groups of a wave hold private partial sums: combine them (every lane ends up with the total of its piece)
+template <int VEC, int LPR, int CH>
+__device__ inline void spmm_combine(typename VecT<VEC>::type (&acc)[CH])
+{
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) acc[ch] = vadd(acc[ch], vshfl_xor(acc[ch], off));
+}
+
+template <int VEC, int LPR, int CH, int U>
+__device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                       int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
+                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr},
+                                       int pad_col = 0)
+{
     const int lane = threadIdx.x & 63;
-    const int g = lane / LPR;
     const int l = lane % LPR;
     // column offset of each chunk this lane covers; lanes past the row width read column 0 and
     // are never written back
@@ -34,7 +90,7 @@ __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const
     }
     for (int64_t base = begin; base < end; base += 64) {
         int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-        int c = 0;       // column 0 is always a valid row of E: padding slots read it, masked below
+        int c = pad_col;   // a valid row of E (column 0 unless the caller's table starts elsewhere): padding slots read it, masked below
         float v = 0.f;
         if (lane < cnt) {
             c = colidx[base + lane];
@@ -54,49 +110,9 @@ __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const
             v = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(v)));
             cnt = __popcll(m);
         }
-        int j = 0;
-        for (; j + G * U <= cnt; j += G * U) {          // full batches: every slot is a real entry
-            V x[U][CH];
-            float vv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = j + u * G + g;
-                const int cc = __shfl(c, idx);
-                vv[u] = __shfl(v, idx);
-                const float *src = E + (int64_t)cc * ldE;
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) acc[ch] = vfma(vv[u], x[u][ch], acc[ch]);
-        }
-        if (j < cnt) {                                   // tail batch: slots past cnt are masked
-            V x[U][CH];
-            float vv[U];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = j + u * G + g;
-                ok[u] = idx < cnt;
-                const int cc = __shfl(c, idx & 63);
-                vv[u] = __shfl(v, idx & 63);
-                const float *src = E + (int64_t)cc * ldE;
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) x[u][ch] = *reinterpret_cast<const V *>(src + coff[ch]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch) acc[ch] = vsel(ok[u], vfma(vv[u], x[u][ch], acc[ch]), acc[ch]);
-        }
+        spmm_consume<VEC, LPR, CH, U>(c, v, cnt, E, ldE, coff, acc);
     }
-    // combine the G lane groups
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) acc[ch] = vadd(acc[ch], vshfl_xor(acc[ch], off));
+    spmm_combine<VEC, LPR, CH>(acc);
 }
 
 template <int VEC, int LPR, int CH>

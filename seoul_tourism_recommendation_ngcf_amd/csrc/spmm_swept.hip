@@ -543,16 +543,6 @@ bool swept_usable(const ngcf_csr *c, int64_t ldE, int d)
     return true;
 }
 
-// value of lane U of this lane's 16-lane row (DPP row_newbcast: one VALU op, no LDS round trip)
-template <int U> __device__ inline int row_bcast(int x)
-{
-    return __builtin_amdgcn_update_dpp(0, x, 0x150 + U, 0xf, 0xf, false);
-}
-template <int U> __device__ inline float row_bcast(float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + U, 0xf, 0xf, false));
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // RW accumulator rows per wave, NW waves per workgroup (NW*RW*256 B of LDS)

@@ -274,6 +274,45 @@ def test_spmm_matches_c_oracle(d, dev, oracle_clib):
     np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
 
 
+def test_default_segment_length_follows_the_matrix_size(dev, oracle_clib):
+    """A Seoul-shaped product (5 840 user rows of ~75 entries, 100 item rows of ~4 400: BASELINE configs 0-1) is latency-bound on
+    a few hundred waves if its long rows are cut every 2 048 entries; the constructors plan with the power of two in
+    [64, 2048] that gives >= 4 096 segments (256 at 876 K entries), and the result stays the oracle's."""
+    eng = _pkg().engine
+    rng = np.random.default_rng(7)
+    U, I, per_user = 5840, 100, 75
+    u = np.repeat(np.arange(U, dtype=np.int64), per_user)
+    i = np.concatenate([rng.choice(I, per_user, replace=False) for _ in range(U)]).astype(np.int64)
+    rows = np.concatenate([u, i + U])
+    cols = np.concatenate([i + U, u])
+    vals = rng.normal(0, 0.3, rows.size).astype(np.float32)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    N = U + I
+    csr = eng.LaplacianCSR.from_coo(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev),
+                                    torch.from_numpy(vals).to(dev), N, N)
+    lens = np.bincount(rows, minlength=N)
+    assert csr.nnz == 876_000 and csr.n_segments == sum(-(-int(k) // 256) for k in lens if k > 256)
+    rowptr = np.zeros(N + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    # the user rows gather from 100 table rows: their blocks run on the table-in-LDS kernel (spmm_ldstab_kernel), whole and
+    # partial 64-float slices; mode 1 keeps everything on the plain row-wise kernel
+    for d in (64, 4, 96, 512, 200):
+        E = rng.normal(0, 0.5, (N, d)).astype(np.float32)
+        want = c_spmm(oracle_clib, rowptr, cols.astype(np.int32), vals, E)
+        Ed = torch.from_numpy(E).to(dev)
+        got = eng.spmm(csr, Ed).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
+        csr.set_mode(1)
+        plain = eng.spmm(csr, Ed).cpu().numpy()
+        csr.set_mode(0)
+        np.testing.assert_allclose(plain, want, atol=ATOL, rtol=RTOL)
+        np.testing.assert_allclose(got, plain, atol=2e-6, rtol=2e-5)
+    small = eng.LaplacianCSR.from_coo(torch.from_numpy(rows[:5000]).to(dev), torch.from_numpy(cols[:5000]).to(dev),
+                                      torch.from_numpy(vals[:5000]).to(dev), N, N)
+    assert small.n_segments == sum(-(-int(k) // 64) for k in np.bincount(rows[:5000], minlength=N) if k > 64)
+
+
 @pytest.mark.parametrize("d,order", [(64, "cols"), (128, "cols"), (256, "cols"), (128, "rows")])
 def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, monkeypatch):
     """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the L2-swept
