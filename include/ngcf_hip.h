@@ -190,6 +190,15 @@ int ngcf_gather_rows_f32(const float *table, int64_t ld, int d, const int64_t *i
                          int64_t row_off, int64_t n_idx_rows, float *out, int64_t ldo,
                          int32_t *status, void *stream);
 
+/* The three gathers of NGCF.forward (NGCF.py:151-155: users, positive items, negative items) from one table in ONE launch:
+ * out_k[b, 0:d] = table[(row_off_k + idx_k[b]), 0:d] for k = 0, 1, 2; a set with B_k == 0 is skipped (no negative items:
+ * NGCF.py:153).  Same bounds rule and status word as ngcf_gather_rows_f32; the three outputs share the leading dimension. */
+int ngcf_gather_rows3_f32(const float *table, int64_t ld, int d,
+                          const int64_t *idx0, int64_t B0, int64_t row_off0, int64_t n_idx_rows0, float *out0,
+                          const int64_t *idx1, int64_t B1, int64_t row_off1, int64_t n_idx_rows1, float *out1,
+                          const int64_t *idx2, int64_t B2, int64_t row_off2, int64_t n_idx_rows2, float *out2,
+                          int64_t ldo, int32_t *status, void *stream);
+
 /* ---- BPR (bprloss.py:15-22) ------------------------------------------------------------- */
 /*
  * loss = (-sum_r logsigmoid(|u_r.p_r| - |u_r.n_r|) + wd*(sum|u|^2 + sum|p|^2 + sum|n|^2)) / batch_size

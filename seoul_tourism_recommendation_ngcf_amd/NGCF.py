@@ -282,10 +282,10 @@ class NGCF(nn.Module):
             if n_idx is not None:
                 neg_i_embeddings = outs[2]
         else:
-            u_embeddings = _eng.gather_rows(self.all_users_emb, u_idx, status)          # NGCF.py:151
-            pos_i_embeddings = _eng.gather_rows(self.all_items_emb, p_idx, status)      # NGCF.py:152
-            if n_idx is not None:
-                neg_i_embeddings = _eng.gather_rows(self.all_items_emb, n_idx, status)  # NGCF.py:155
+            u_embeddings, pos_i_embeddings, neg = _eng.gather_rows3(                       # NGCF.py:151-155, one launch
+                self._all_E, ((u_idx, 0, self.n_user), (p_idx, self.n_user, self.n_item), (n_idx, self.n_user, self.n_item)), status)
+            if neg is not None:
+                neg_i_embeddings = neg
         if self.check_indices:
             if int(status.item()) != 0:
                 status.zero_()

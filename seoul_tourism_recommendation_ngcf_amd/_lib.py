@@ -54,6 +54,7 @@ PROTOTYPES = {
     "ngcf_feature_inject_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_i64), C.c_int, _vp, _i64, C.c_double, _vp, _vp, _vp]),
     "ngcf_gather_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "ngcf_gather_rows3_f32": (C.c_int, [_vp, _i64, C.c_int] + [_vp, _i64, _i64, _i64, _vp] * 3 + [_i64, _vp, _vp]),
     "ngcf_bpr_workspace_bytes": (_i64, [_i64]),
     "ngcf_bpr_fused_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp]),
     "ngcf_bpr_backward_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -280,9 +280,7 @@ class GatherTriple(torch.autograd.Function):
     def forward(ctx, all_E, n_user, status, u_idx, p_idx, n_idx):
         U = int(n_user)
         n_item = int(all_E.shape[0]) - U
-        u = _eng.gather_rows(all_E, u_idx, status, 0, U)
-        p = _eng.gather_rows(all_E, p_idx, status, U, n_item)
-        n = _eng.gather_rows(all_E, n_idx, status, U, n_item) if n_idx is not None else None
+        u, p, n = _eng.gather_rows3(all_E, ((u_idx, 0, U), (p_idx, U, n_item), (n_idx, U, n_item)), status)
         ctx.shape, ctx.U, ctx.has_n = tuple(all_E.shape), U, n_idx is not None
         ctx.save_for_backward(u_idx, p_idx, *([n_idx] if n_idx is not None else []))
         return (u, p, n) if n is not None else (u, p)

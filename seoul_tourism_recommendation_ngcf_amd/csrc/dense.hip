@@ -394,10 +394,13 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
         };
         // Two chunks of look-ahead in two fixed register sets (no rotation copies - a copy of a register that is still being
         // loaded is a wait): the sums and products of a chunk are formed first, which frees its set for the chunk after next.
+        // Every prefetch is UNCONDITIONAL (past the end the last chunk is read again and never used): behind a branch the
+        // compiler cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) at the next use - the
+        // look-ahead then exists in the source only.  The odd last chunk is peeled off the loop for the same reason.
+        const int last = n_chunks - 1;
         f32x4 la0, lb0, ea0, eb0, la1, lb1, ea1, eb1;
         fetch(0, la0, lb0, ea0, eb0);
-        la1 = la0, lb1 = lb0, ea1 = ea0, eb1 = eb0;
-        if (n_chunks > 1) fetch(1, la1, lb1, ea1, eb1);
+        fetch(last < 1 ? last : 1, la1, lb1, ea1, eb1);
         auto chunk_mfma = [&](int c, const f32x4 (&a4)[4]) {
             const float *wc = W + (int64_t)c * NGCF_KC * WCOLS;
 #pragma unroll
@@ -412,21 +415,27 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
                 }
             }
         };
-        for (int c = 0; c < n_chunks; c += 2) {
+        int c = 0;
+        for (; c + 1 < n_chunks; c += 2) {
             {
                 f32x4 a4[4];
                 form(c, la0, lb0, ea0, eb0, a4);
-                if (c + 2 < n_chunks) fetch(c + 2, la0, lb0, ea0, eb0);               // in flight under two chunks of MFMAs
+                fetch(c + 2 < last ? c + 2 : last, la0, lb0, ea0, eb0);               // in flight under two chunks of MFMAs
                 __builtin_amdgcn_sched_barrier(0);      // (left alone the compiler sinks these loads to just before their use)
                 chunk_mfma(c, a4);
             }
-            if (c + 1 < n_chunks) {
+            {
                 f32x4 a4[4];
                 form(c + 1, la1, lb1, ea1, eb1, a4);
-                if (c + 3 < n_chunks) fetch(c + 3, la1, lb1, ea1, eb1);
+                fetch(c + 3 < last ? c + 3 : last, la1, lb1, ea1, eb1);
                 __builtin_amdgcn_sched_barrier(0);
                 chunk_mfma(c + 1, a4);
             }
+        }
+        if (c < n_chunks) {
+            f32x4 a4[4];
+            form(c, la0, lb0, ea0, eb0, a4);
+            chunk_mfma(c, a4);
         }
         // ---- epilogue (wave-local): bias, LeakyReLU, dropout, row norm, stores
         const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -511,6 +520,176 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 / 512 output columns with NO operand in LDS (r02).  At these widths a workgroup of layer_dense_kernel owns 32 (or 64) rows
+// and each of its waves its own 128 output columns: the weights a wave multiplies by are shared with nobody, yet a 32 / 64 KB
+// chunk of them goes through the one LDS buffer per chunk between two barriers, and with a few thousand rows (the Seoul graph:
+// 186 workgroups, one wave per SIMD) nothing hides that.  Here a wave reads its B operands - the lane's four tile values of a
+// k-pair are 16 contiguous bytes of the packed row - straight from the L2-resident packed matrix into registers, one chunk ahead
+// in two fixed register sets, and its A operands like layer_dense_resident_kernel; the only LDS traffic is the exchange of the
+// row sums of squares at the end.  Same k order per output element as the other two kernels: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NT> struct TileVec;
+template <> struct TileVec<4> { using type = f32x4; };
+template <> struct TileVec<2> { using type = f32x2; };
+
+template <int CW, int NT>
+__global__ __launch_bounds__(CW * 64) void layer_dense_direct_kernel(
+    const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ Es, int64_t ldE, int64_t n_rows, int d_in, int d_out,
+    const float *__restrict__ Wt, const float *__restrict__ bias2, int n_chunks, float leaky, float drop_p, uint64_t drop_seed,
+    const float *__restrict__ drop_mask, int64_t ldm, float *__restrict__ carry, int64_t ldc, float *__restrict__ norm, int64_t ldn)
+{
+    constexpr int WCOLS = 32 * NT * CW;            // weights packed with this NT: a lane's NT tile values are contiguous
+    using BV = typename TileVec<NT>::type;
+    __shared__ float ssq[32 * CW];
+    const int tid = threadIdx.x, cw = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    int64_t grow_l = row0 + li;
+    grow_l = grow_l < n_rows ? grow_l : n_rows - 1;              // rows past the end re-read the last row, never stored
+    const float *le_row = LE + grow_l * ldLE, *e_row = Es + grow_l * ldE;
+    const int d4 = (d_in + 3) & ~3;
+    const float *Wl = Wt + (int64_t)lh * 4 * WCOLS + cw * (32 * NT) + li * NT;   // k-pair (kb, sx) of chunk c: + ((c*32 + kb*8 + sx) * WCOLS)
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    auto fetch_a = [&](int c, f32x4 &la, f32x4 &lb, f32x4 &ea, f32x4 &eb) {
+        const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
+        const int cca = ca < d4 ? ca : d4 - 4, ccb = cb < d4 ? cb : d4 - 4;
+        la = *reinterpret_cast<const f32x4 *>(le_row + cca);
+        ea = *reinterpret_cast<const f32x4 *>(e_row + cca);
+        lb = *reinterpret_cast<const f32x4 *>(le_row + ccb);
+        eb = *reinterpret_cast<const f32x4 *>(e_row + ccb);
+    };
+    auto fetch_b = [&](int c, BV (&b)[16]) {
+        const float *wc = Wl + (int64_t)c * NGCF_KC * WCOLS;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) b[q] = *reinterpret_cast<const BV *>(wc + ((q >> 2) * 8 + (q & 3)) * WCOLS);
+    };
+    auto form = [&](int c, f32x4 la, f32x4 lb, f32x4 ea, f32x4 eb, f32x4 (&a4)[4]) {   // zeroing of the columns past d_in at use
+        const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
+        if (cb + 4 > d_in) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ca + q >= d_in) la[q] = 0.f, ea[q] = 0.f;
+                if (cb + q >= d_in) lb[q] = 0.f, eb[q] = 0.f;
+            }
+        }
+        a4[0] = la + ea, a4[1] = lb + eb, a4[2] = la * ea, a4[3] = lb * eb;
+    };
+    auto chunk_mfma = [&](const f32x4 (&a4)[4], const BV (&b)[16]) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const BV bv = b[kb * 4 + sx];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kb][sx], bv[t], acc[t], 0, 0, 0);
+            }
+    };
+    // every prefetch unconditional, the odd last chunk peeled off (see layer_dense_resident_kernel)
+    const int last = n_chunks - 1;
+    f32x4 la0, lb0, ea0, eb0, la1, lb1, ea1, eb1;
+    BV b0[16], b1[16];
+    fetch_a(0, la0, lb0, ea0, eb0);
+    fetch_b(0, b0);
+    fetch_a(last < 1 ? last : 1, la1, lb1, ea1, eb1);
+    fetch_b(last < 1 ? last : 1, b1);
+    int c = 0;
+    for (; c + 1 < n_chunks; c += 2) {
+        {
+            f32x4 a4[4];
+            form(c, la0, lb0, ea0, eb0, a4);
+            fetch_a(c + 2 < last ? c + 2 : last, la0, lb0, ea0, eb0);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk_mfma(a4, b0);
+            fetch_b(c + 2 < last ? c + 2 : last, b0);          // in flight under the next chunk's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            f32x4 a4[4];
+            form(c + 1, la1, lb1, ea1, eb1, a4);
+            fetch_a(c + 3 < last ? c + 3 : last, la1, lb1, ea1, eb1);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk_mfma(a4, b1);
+            fetch_b(c + 3 < last ? c + 3 : last, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (c < n_chunks) {
+        f32x4 a4[4];
+        form(c, la0, lb0, ea0, eb0, a4);
+        chunk_mfma(a4, b0);
+    }
+    // ---- epilogue: bias, LeakyReLU, dropout, row sum of squares (as layer_dense_kernel with RW = 1)
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    float rowss[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = (cw * NT + t) * 32 + li;
+        const float bz = bias2[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + bz;
+            v = v >= 0.f ? v : leaky * v;
+            if (drop_mask) {           // "reference" mode: the noise tensor nn.Dropout drew on the host, NGCF.py:142
+                const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
+            } else if (drop_p > 0.f) {
+                const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                v = h < drop_thr ? 0.f : v * keep_scale;
+            }
+            acc[t][r] = v;
+            rowss[r] = fmaf(v, v, rowss[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = rowss[r];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        rowss[r] = s;
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssq[((r & 3) + 8 * (r >> 2) + 4 * lh) * CW + cw] = rowss[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < CW; ++q) s += ssq[lr * CW + q];
+        rowss[r] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (grow >= n_rows) continue;
+        const float inv = 1.f / fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = (cw * NT + t) * 32 + li;
+            if (col < d_out) {
+                const float v = acc[t][r];
+                if (carry) carry[grow * ldc + col] = v;
+                norm[grow * ldn + col] = v * inv;
+            }
+        }
+    }
+}
+
 static int dense_dop(int d_out)
 {
     if (d_out <= 32) return 32;
@@ -571,9 +750,17 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const int n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
     float *Wt = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
     float *bias2 = Wt + (int64_t)n_chunks * NGCF_KC * dop;
-    pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop, dop <= 128 ? dop / 32 : 4, Wt, bias2);
-    LAUNCH_CHECK();
     const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
+    // 256 / 512 output columns and at most two workgroups per CU (<= 16 384 rows - the Seoul graph has 5 940): operands straight
+    // from global memory / L2, no staging (layer_dense_direct_kernel).  tools/dense_wide_lab.py: 94 vs 114 us at 5 940 x 515 -> 512,
+    // 50 vs 57 us at 256 -> 256; from 100 K rows on the staged kernel (two workgroups share a CU's LDS and matrix pipe) is as fast
+    // or faster (1.08 vs 1.40 ms at 100 K x 512 -> 512).  NGCF_DENSE_DIRECT=0 / 2: never / at any row count.
+    const int direct_env = getenv("NGCF_DENSE_DIRECT") ? atoi(getenv("NGCF_DENSE_DIRECT")) : 1;
+    const bool direct = direct_env && dop >= 256 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
+                        n_rows > 0 && (n_rows <= 16384 || direct_env == 2);
+    pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop,
+                                                                                    dop <= 128 ? dop / 32 : 4, Wt, bias2);
+    LAUNCH_CHECK();
 #define NGCF_DENSE(RW, CW, NT) \
     return launch_dense<RW, CW, NT>(al, n_rows, LE, ldLE, Es, ldEs, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, \
                                     drop_seed, drop_mask, ld_mask, carry, ldc, norm, ldn, stream)
@@ -596,6 +783,19 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
             LAUNCH_CHECK();
             return NGCF_OK;
         }
+    }
+    if (direct) {
+        const int64_t blocks = (n_rows + 31) / 32;
+        if (dop == 256)
+            layer_dense_direct_kernel<2, 4><<<dim3((unsigned)blocks), 128, 0, stream>>>(
+                LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc,
+                norm, ldn);
+        else
+            layer_dense_direct_kernel<4, 4><<<dim3((unsigned)blocks), 256, 0, stream>>>(
+                LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc,
+                norm, ldn);
+        LAUNCH_CHECK();
+        return NGCF_OK;
     }
     switch (dop) {
     case 32: NGCF_DENSE(4, 1, 1);
@@ -638,7 +838,17 @@ extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_
     ws += spmm_ws;
     const int64_t dense_ws = ngcf_dense_workspace_bytes(d_in, d_out);
     void *ws_dense = ws;
-    int rc = ngcf_spmm_csr_f32(c, Eg, ldEg, d_in, LE, ldLE, ws_spmm, spmm_ws, stream);
+    // Widths that are not a multiple of 4 (65, 130, 515: NGCF.py:39-43) on a SMALL matrix: the product is launch-bound, and the
+    // main + tail panel split costs four extra launches (pack, tail product, fix-up, unpack: 23 of 141 us on the Seoul-shaped C1).
+    // When the gathered rows are 16-byte aligned and padded, the columns up to the next multiple of 4 are simply multiplied along:
+    // whatever they hold ends up in the padding columns of LE, which the dense half never reads (it selects zeros there).
+    // (Reading them cannot fault: the 16-byte piece that holds the last column of a 16-byte aligned row is read whole.  The
+    // mirror's engine.spmm applies the same rule to the products of the training path, so both paths give the same bits.)
+    int d_sp = d_in;
+    if (d_in % 4 != 0 && c->nnz < ((int64_t)1 << 22) && ldEg % 4 == 0 && ldEg >= align_up(d_in, 4) && aligned16(Eg) &&
+        !getenv("NGCF_NO_PAD_PRODUCT"))
+        d_sp = (int)align_up(d_in, 4);
+    int rc = ngcf_spmm_csr_f32(c, Eg, ldEg, d_sp, LE, ldLE, ws_spmm, spmm_ws, stream);
     if (rc != NGCF_OK) return rc;
     return ngcf_layer_dense_f32(LE, ldLE, Es, ldEs, c->n_rows, d_in, W1, b1, W2, b2, d_out, leaky, drop_p, drop_seed,
                                 drop_mask, ld_mask, carry, ldc, norm, ldn, ws_dense, dense_ws, stream);

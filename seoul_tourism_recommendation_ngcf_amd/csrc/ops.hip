@@ -195,6 +195,60 @@ extern "C" int ngcf_gather_rows_f32(const float *table, int64_t ld, int d, const
     return NGCF_OK;
 }
 
+// The three gathers of a forward (users, positive items, negative items: NGCF.py:151-155) in one launch: at Seoul sizes a
+// forward is launch-bound and each gather is a 4 us kernel.
+struct GatherSet {
+    const int64_t *idx;
+    int64_t B, row_off, n_idx_rows;
+    float *out;
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows3_kernel(const float *__restrict__ table, int64_t ld, int d, GatherSet s0, GatherSet s1,
+                                                           GatherSet s2, int64_t blocks0, int64_t blocks1, int64_t ldo,
+                                                           int32_t *status)
+{
+    using V = typename VecT<VEC>::type;
+    int64_t blk = blockIdx.x;
+    GatherSet s = s0;
+    if (blk >= blocks0 + blocks1) s = s2, blk -= blocks0 + blocks1;
+    else if (blk >= blocks0) s = s1, blk -= blocks0;
+    const int64_t b = blk * 4 + (threadIdx.x >> 6);
+    if (b >= s.B) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = s.idx[b];
+    if (i < 0 || i >= s.n_idx_rows) {
+        if (lane == 0) atomicOr(status, 1);
+        return;
+    }
+    const float *src = table + (s.row_off + i) * ld;
+    float *dst = s.out + b * ldo;
+    for (int o = lane * VEC; o < d; o += 64 * VEC) *reinterpret_cast<V *>(dst + o) = *reinterpret_cast<const V *>(src + o);
+}
+
+extern "C" int ngcf_gather_rows3_f32(const float *table, int64_t ld, int d, const int64_t *idx0, int64_t B0, int64_t row_off0,
+                                     int64_t n_rows0, float *out0, const int64_t *idx1, int64_t B1, int64_t row_off1,
+                                     int64_t n_rows1, float *out1, const int64_t *idx2, int64_t B2, int64_t row_off2,
+                                     int64_t n_rows2, float *out2, int64_t ldo, int32_t *status, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B0 < 0 || B1 < 0 || B2 < 0) return fail(NGCF_ERR_ARG, "gather_rows3: negative batch");
+    if (B0 + B1 + B2 == 0) return NGCF_OK;
+    if (!table || !status || d <= 0 || ld < d || ldo < d || (B0 && (!idx0 || !out0)) || (B1 && (!idx1 || !out1)) ||
+        (B2 && (!idx2 || !out2)))
+        return fail(NGCF_ERR_ARG, "gather_rows3: bad argument");
+    const bool vec = d % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && aligned16(table) && (!B0 || aligned16(out0)) &&
+                     (!B1 || aligned16(out1)) && (!B2 || aligned16(out2));
+    const int64_t k0 = (B0 + 3) / 4, k1 = (B1 + 3) / 4, k2 = (B2 + 3) / 4;
+    if (k0 + k1 + k2 >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "gather_rows3: too many rows for one launch");
+    const GatherSet s0{idx0, B0, row_off0, n_rows0, out0}, s1{idx1, B1, row_off1, n_rows1, out1}, s2{idx2, B2, row_off2, n_rows2, out2};
+    if (vec)
+        gather_rows3_kernel<4><<<dim3((unsigned)(k0 + k1 + k2)), 256, 0, stream>>>(table, ld, d, s0, s1, s2, k0, k1, ldo, status);
+    else
+        gather_rows3_kernel<1><<<dim3((unsigned)(k0 + k1 + k2)), 256, 0, stream>>>(table, ld, d, s0, s1, s2, k0, k1, ldo, status);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // BPR, bprloss.py:15-22
 // ---------------------------------------------------------------------------------------------

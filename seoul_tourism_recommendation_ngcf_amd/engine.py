@@ -6,6 +6,7 @@ used for device memory and streams only; no tensor arithmetic of the hot path ha
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -172,8 +173,16 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
     d = int(E.shape[1])
     if E.shape[0] != csr.n_cols:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({csr.n_rows}x{csr.n_cols} and {tuple(E.shape)})")
+    d_view = d
     if out is None:     # rows padded to a multiple of 32 floats (128-byte aligned rows: the float4 / swept kernels apply at any d)
         out = torch.empty((csr.n_rows, (d + 31) // 32 * 32), dtype=torch.float32, device=E.device)[:, :d]
+        # the rule of ngcf_layer_fused_f32 (csrc/dense.hip), so that both forward paths produce the same bits: a width that is
+        # not a multiple of 4 on a small (launch-bound) matrix is multiplied up to the next multiple of 4 when the gathered rows
+        # are 16-byte aligned and padded - the extra columns land in the padding of `out`
+        d4 = (d + 3) // 4 * 4
+        if d4 != d and csr.nnz < (1 << 22) and E.stride(0) % 4 == 0 and E.stride(0) >= d4 and E.data_ptr() % 16 == 0 and \
+                not os.environ.get("NGCF_NO_PAD_PRODUCT"):
+            d = d4
     ws = ws or Workspace()
     nb = csr.spmm_workspace_bytes(d)
     w = ws.get(nb, E.device)
@@ -187,6 +196,7 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
             _lib.check(lib.ngcf_spmm_csr_dropout_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
                                                      _row_major_ld(out, "out"), float(p), arr, len(seeds), _ptr(eid),
                                                      _ptr(w), w.numel(), _stream()))
+    assert out.shape[1] == d_view
     return out
 
 
@@ -284,6 +294,27 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor, ro
         _lib.check(lib.ngcf_gather_rows_f32(_ptr(table), _row_major_ld(table, "table"), d, _ptr(idx), B, row_off,
                                             n_idx_rows, _ptr(out), d, _ptr(status), _stream()))
     return out
+
+
+def gather_rows3(table: torch.Tensor, sets, status: torch.Tensor):
+    """The (users, positive items, negative items) gathers of NGCF.py:151-155 in one launch.  `sets` = three
+    `(idx or None, row_off, n_idx_rows)`; returns three fresh tensors (`None` where idx is None).  Bit-exact copies."""
+    lib = _lib.load()
+    _f32c(table, "table")
+    d = int(table.shape[1])
+    args, outs = [], []
+    for idx, row_off, n_rows in sets:
+        if idx is None:
+            args += [None, 0, 0, 0, None]
+            outs.append(None)
+            continue
+        idx = idx.to(device=table.device, dtype=torch.int64).contiguous()
+        out = torch.empty((int(idx.numel()), d), dtype=torch.float32, device=table.device)
+        args += [_ptr(idx), int(idx.numel()), int(row_off), int(n_rows), _ptr(out)]
+        outs.append(out)
+    with torch.cuda.device(table.device):
+        _lib.check(lib.ngcf_gather_rows3_f32(_ptr(table), _row_major_ld(table, "table"), d, *args, d, _ptr(status), _stream()))
+    return outs
 
 
 def feature_inject(user_w: torch.Tensor, tables: Sequence[torch.Tensor], idx: Sequence[torch.Tensor],

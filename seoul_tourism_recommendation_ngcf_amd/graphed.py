@@ -72,10 +72,10 @@ class GraphedForward:
             w1, b1, w2, b2 = m._layer_params()
             all_E = propagate_forward(self.bufs, [self.csr] * m.n_layer, m.user_embedding.weight, m.item_embedding.weight,
                                       w1, b1, w2, b2, [0.0] * m.n_layer, [0] * m.n_layer)
-            users, items = all_E[:m.n_user], all_E[m.n_user:]
-            u = _eng.gather_rows(users, i["u_id"], self.status)
-            p = _eng.gather_rows(items, i["pos_item"], self.status)
-            n = _eng.gather_rows(items, i["neg_item"], self.status) if self.with_neg else torch.empty(0)
+            u, p, n = _eng.gather_rows3(all_E, ((i["u_id"], 0, m.n_user), (i["pos_item"], m.n_user, m.n_item),
+                                                (i["neg_item"] if self.with_neg else None, m.n_user, m.n_item)), self.status)
+            if n is None:
+                n = torch.empty(0)
         return all_E, u, p, n
 
     def __call__(self, u_id, age, sex, month, day, dow, pos_item, neg_item=None, year=None, node_flag=False):

@@ -580,6 +580,18 @@ def test_gather_rows_bit_exact_and_bounds(d, dev):
     assert int(status.item()) != 0
     out0 = eng.gather_rows(table, idx[:0], status)
     assert out0.shape == (0, d)
+    # the three gathers of a forward in one launch (NGCF.py:151-155): users [0, 100), items [100, 500); no negative items
+    status.zero_()
+    u_idx = torch.randint(0, 100, (33,), generator=g).to(dev)
+    n_idx = torch.randint(0, 400, (5,), generator=g).to(dev)
+    u, p, n = eng.gather_rows3(table, ((u_idx, 0, 100), (idx, 100, 400), (n_idx, 100, 400)), status)
+    assert torch.equal(u, table[u_idx]) and torch.equal(p, table[100:][idx]) and torch.equal(n, table[100:][n_idx])
+    u, p, n = eng.gather_rows3(table, ((u_idx, 0, 100), (idx, 100, 400), (None, 100, 400)), status)
+    assert n is None and torch.equal(u, table[u_idx]) and torch.equal(p, table[100:][idx]) and int(status.item()) == 0
+    u, p, n = eng.gather_rows3(table, ((u_idx[:0], 0, 100), (idx[:0], 100, 400), (None, 100, 400)), status)
+    assert u.shape == (0, d) and p.shape == (0, d)
+    eng.gather_rows3(table, ((u_idx + 100, 0, 100), (idx, 100, 400), (n_idx, 100, 400)), status)   # a user id past the users
+    assert int(status.item()) != 0
 
 
 def test_forward_raises_index_error_and_shape_error(dev):
@@ -869,3 +881,42 @@ def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, m
             frac = float((outs[0][0] == 0).float().mean())
             assert abs(frac - 0.3) < 0.01
     assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("d_in,d_out,n,mode", [(515, 512, 5941, "eval"), (512, 512, 300, "hash"), (256, 256, 4099, "mask"),
+                                              (130, 200, 1000, "last"), (260, 300, 33, "eval"), (8, 512, 64, "hash"),
+                                              (256, 256, 40_003, "eval")])
+def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, mode, dev):
+    """layer_dense_direct_kernel (256 / 512 output columns, operands straight from global memory, no LDS staging) against
+    layer_dense_kernel on the same inputs: same k order per output element, so carry and normalised block agree bit for bit -
+    eval mode, hash dropout, host-drawn noise, no carry, output widths below the padded width, partial last tiles."""
+    import os
+    eng = _pkg().engine
+    g = torch.Generator().manual_seed(d_in + d_out + n)
+    ld = (d_in + 31) // 32 * 32
+    LE = (torch.randn((n, ld), generator=g) * 0.5).to(dev)[:, :d_in]
+    E = (torch.randn((n, ld), generator=g) * 0.5).to(dev)[:, :d_in]
+    W1, W2 = ((torch.randn((d_out, d_in), generator=g) * 0.1).to(dev) for _ in range(2))
+    b1, b2 = ((torch.randn((d_out,), generator=g) * 0.1).to(dev) for _ in range(2))
+    mask = (torch.rand((n, d_out), generator=g) > 0.3).float().to(dev) / 0.7 if mode == "mask" else None
+    kw = dict(drop_p=0.3 if mode in ("hash", "mask") else 0.0, drop_seed=77 if mode == "hash" else 0, drop_mask=mask)
+    outs = []
+    try:
+        for direct in ("2", "0"):
+            os.environ["NGCF_DENSE_DIRECT"] = direct
+            carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
+            norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]            # a column slice of a wider matrix
+            eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
+            outs.append((carry, norm.clone()))
+    finally:
+        del os.environ["NGCF_DENSE_DIRECT"]
+    assert torch.equal(outs[0][1], outs[1][1])
+    if mode != "last":
+        assert torch.equal(outs[0][0], outs[1][0])
+    assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
+    # and against the plain formula (NGCF.py:131-146, eval mode) on the rows of the first tile
+    if mode == "eval":
+        le, e = LE[:32].double(), E[:32].double()
+        m = (le + e) @ W1.double().T + b1.double() + (le * e) @ W2.double().T + b2.double() + b1.double()
+        m = torch.nn.functional.leaky_relu(m, 0.2)
+        torch.testing.assert_close(outs[0][0][:32].double(), m, atol=2e-5, rtol=1e-4)

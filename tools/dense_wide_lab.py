@@ -1,0 +1,42 @@
+"""Wide dense layers (256 / 512 output columns): layer_dense_direct_kernel against the staged layer_dense_kernel at Seoul-sized and
+large row counts."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
+eng = pkg.engine
+dev = torch.device("cuda:0")
+
+
+def t(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for n, d_in, d_out in ((5940, 515, 512), (5940, 512, 512), (5940, 256, 256), (100_000, 512, 512), (100_000, 256, 256),
+                       (1_100_000, 256, 256), (1_100_000, 512, 512)):
+    ld = (d_in + 31) // 32 * 32
+    LE = torch.randn((n, ld), device=dev)[:, :d_in]
+    E = torch.randn((n, ld), device=dev)[:, :d_in]
+    W1, W2 = (torch.randn((d_out, d_in), device=dev) * 0.1 for _ in range(2))
+    b1, b2 = (torch.randn((d_out,), device=dev) * 0.1 for _ in range(2))
+    carry = torch.empty((n, d_out), device=dev)
+    norm = torch.empty((n, d_out), device=dev)
+    ws = eng.Workspace()
+    res = {}
+    for direct in ("2", "0"):
+        os.environ["NGCF_DENSE_DIRECT"] = direct
+        res[direct] = t(lambda: eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, ws))
+    fl = 4.0 * n * d_in * d_out
+    print(f"n={n} {d_in}->{d_out}: direct {res['2']*1e3:.1f} us ({fl/res['2']/1e9:.1f} TF), staged {res['0']*1e3:.1f} us "
+          f"({fl/res['0']/1e9:.1f} TF)", flush=True)
+    del LE, E, carry, norm
