@@ -544,6 +544,9 @@ bool swept_usable(const ngcf_csr *c, int64_t ldE, int d)
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef NGCF_SWEPT_LABW
+#define NGCF_SWEPT_LABW 3      // loads allowed in flight when the adds of a half-chunk begin (see load_entries below)
+#endif
 
 // RW accumulator rows per wave, NW waves per workgroup (NW*RW*256 B of LDS)
 // DBG: every kDbgEvery chunks a wave stores (s_memrealtime, column it is gathering) into `dbg` - the sweep-spread
@@ -655,19 +658,28 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
                 }
             };
             const int idle_pk = end > beg ? (RW << kRowBits) | (e_pack[beg] & kColMask) : 0;   // past the end: like an empty slot
+            // Every load of the main loop is UNCONDITIONAL (slots past the end of the list read the list's last entry again and
+            // are turned into idle slots afterwards): behind a branch the compiler cannot count a load and waits for everything
+            // in flight instead - which is what r01/r02 ran with unknowingly (s_waitcnt vmcnt(7..0) in front of the adds of a
+            // half: at most the other half's eight gathers in flight).  With exact counts (vmcnt(15..8): both halves in flight)
+            // the product is SLOWER - 3.16 vs 2.96-2.99 ms per L.E on C3 - because waves that run further ahead of their
+            // data spread the sweep; so the depth is now stated: all but NGCF_SWEPT_LABW loads have arrived before the adds
+            // of a half begin.  C3, ms per L.E, same box: 0 -> 2.99-3.00, 2 -> 2.94, 3 -> 2.95, 4 -> 2.95 (3.05 once), 5 -> 2.96,
+            // 6 -> 2.97, 8 -> 3.16, 12 -> 3.13, no explicit wait -> 3.16-3.18.
             auto load_entries = [&](int64_t pos, int &pk, float &v) {
                 const int64_t idx = pos + held;
-                pk = idle_pk;
-                v = 0.f;
-                if (idx < end) {
-                    if (nt_flags & 1) {          // the entry lists are read once: streaming loads, they should not displace table rows in L2
-                        pk = __builtin_nontemporal_load(&e_pack[idx]);
-                        v = __builtin_nontemporal_load(&e_val[idx]);
-                    } else {
-                        pk = e_pack[idx];
-                        v = e_val[idx];
-                    }
+                const int64_t idc = idx < end ? idx : end - 1;
+                int pk_l;
+                float v_l;
+                if (nt_flags & 1) {              // the entry lists are read once: streaming loads, they should not displace table rows in L2
+                    pk_l = __builtin_nontemporal_load(&e_pack[idc]);
+                    v_l = __builtin_nontemporal_load(&e_val[idc]);
+                } else {
+                    pk_l = e_pack[idc];
+                    v_l = e_val[idc];
                 }
+                pk = idx < end ? pk_l : idle_pk;
+                v = idx < end ? v_l : 0.f;
             };
             if (end > beg) {
                 int pkA, pkB;
@@ -728,18 +740,15 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
                         }
                     }
                     load_entries(pos + kCH, pkB, vB);                // the next chunk's entries, two gathers ahead
-                    const bool hi = pos + 8 * kEPR < end;
-                    if (hi) {
-                        cross(pos + 8 * kEPR, false);                // no gather is issued into a window before its permission
-                        NGCF_GATHER_HI(xb)
-                    }
+                    if (pos + 8 * kEPR < end) cross(pos + 8 * kEPR, false);   // no gather is issued into a window before its permission
+                    NGCF_GATHER_HI(xb)                               // (past the end: idle slots, the column of the task's first entry)
+                    __builtin_amdgcn_s_waitcnt(0xF70 | (NGCF_SWEPT_LABW & 0xf));   // s_waitcnt vmcnt(NGCF_SWEPT_LABW)
                     NGCF_ACC_LO(xa)
-                    if (pos + kCH < end) {
-                        cross(pos + kCH, false);
-                        offA = (unsigned)(pkB & kColMask) * ld_bytes;
-                        NGCF_GATHER_LO(xa)                           // first half of the next chunk, in flight during the adds below
-                    }
-                    if (hi) { NGCF_ACC_HI(xb) }
+                    if (pos + kCH < end) cross(pos + kCH, false);
+                    offA = (unsigned)(pkB & kColMask) * ld_bytes;
+                    NGCF_GATHER_LO(xa)                               // first half of the next chunk, in flight during the adds below
+                    __builtin_amdgcn_s_waitcnt(0xF70 | (NGCF_SWEPT_LABW & 0xf));
+                    NGCF_ACC_HI(xb)
                     pkA = pkB;
                     vA = vB;
                 }
