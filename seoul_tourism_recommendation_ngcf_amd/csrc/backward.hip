@@ -387,7 +387,7 @@ __global__ void bwd_input_pack_kernel(const float *__restrict__ W1, const float 
 // NT 32x32 tiles per wave: a panel of 32*NT input columns (NT = 4: 128; NT = 5: 160, which takes the reference's 130-wide
 // first layer in one panel instead of two)
 template <int NT>
-__global__ __launch_bounds__(256) void layer_bwd_input_kernel(const float *__restrict__ dM, int64_t ldM, int64_t n_rows, int d_out,
+__global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__restrict__ dM, int64_t ldM, int64_t n_rows, int d_out,
                                                               const float *__restrict__ Wp, int n_chunks,
                                                               const float *__restrict__ LE, int64_t ldLE,
                                                               const float *__restrict__ E, int64_t ldE, int d_in, int col0,
