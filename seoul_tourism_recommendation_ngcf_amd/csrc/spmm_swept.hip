@@ -545,7 +545,7 @@ bool swept_usable(const ngcf_csr *c, int64_t ldE, int d)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef NGCF_SWEPT_LABW
-#define NGCF_SWEPT_LABW 3      // loads allowed in flight when the adds of a half-chunk begin (see load_entries below)
+#define NGCF_SWEPT_LABW 2      // loads allowed in flight when the adds of a half-chunk begin (see load_entries below)
 #endif
 
 // RW accumulator rows per wave, NW waves per workgroup (NW*RW*256 B of LDS)
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
             // the product is SLOWER - 3.16 vs 2.96-2.99 ms per L.E on C3 - because waves that run further ahead of their
             // data spread the sweep; so the depth is now stated: all but NGCF_SWEPT_LABW loads have arrived before the adds
             // of a half begin.  C3, ms per L.E, same box: 0 -> 2.99-3.00, 2 -> 2.94, 3 -> 2.95, 4 -> 2.95 (3.05 once), 5 -> 2.96,
-            // 6 -> 2.97, 8 -> 3.16, 12 -> 3.13, no explicit wait -> 3.16-3.18.
+            // 6 -> 2.97, 8 -> 3.16, 12 -> 3.13, no explicit wait -> 3.16-3.18 (0..6 are within run-to-run noise of each other: +-0.04).
             auto load_entries = [&](int64_t pos, int &pk, float &v) {
                 const int64_t idx = pos + held;
                 const int64_t idc = idx < end ? idx : end - 1;
