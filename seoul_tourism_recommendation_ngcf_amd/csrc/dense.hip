@@ -359,26 +359,47 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
     float bz[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bz[t] = bias2[t * 32 + li];
-    for (int64_t tile = (int64_t)blockIdx.x * kResWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kResWaves) {
+    // Stores and loads share one in-order counter (vmcnt), so a wave that stores its finished tile and THEN asks for the first
+    // chunks of its next tile waits for all 256 stores to be acknowledged before its first MFMA: the per-tile cost that no
+    // staggering of the waves could hide.  The first two chunks of the next tile are therefore requested BEFORE the epilogue of
+    // the current one; by the time anything younger than the stores is waited for, two chunks of MFMAs have passed.
+    const int last = n_chunks - 1;
+    const int64_t tile_step = (int64_t)gridDim.x * kResWaves;
+    auto row_of = [&](int64_t t) {                 // the lane's row of tile t (rows past the end re-read the last row, never stored)
+        int64_t g = t * 32 + li;
+        return g < n_rows ? g : n_rows - 1;
+    };
+    // the lane's four 16-byte pieces of a chunk: LE and E at columns c*16 + lh*4 (a) and c*16 + 8 + lh*4 (b); columns past
+    // d_in are re-read from the row's last float4 and zeroed
+    auto fetch = [&](const float *le_row, const float *e_row, int c, f32x4 &la, f32x4 &lb, f32x4 &ea, f32x4 &eb) {
+        const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
+        const int cca = ca < d4 ? ca : d4 - 4, ccb = cb < d4 ? cb : d4 - 4;
+        la = *reinterpret_cast<const f32x4 *>(le_row + cca);
+        ea = *reinterpret_cast<const f32x4 *>(e_row + cca);
+        lb = *reinterpret_cast<const f32x4 *>(le_row + ccb);
+        eb = *reinterpret_cast<const f32x4 *>(e_row + ccb);
+    };
+    // Two chunks of look-ahead in two fixed register sets (no rotation copies - a copy of a register that is still being
+    // loaded is a wait): the sums and products of a chunk are formed first, which frees its set for the chunk after next.
+    // Every prefetch is UNCONDITIONAL (past the end the last chunk is read again and never used): behind a branch the
+    // compiler cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) at the next use - the
+    // look-ahead then exists in the source only.  The odd last chunk is peeled off the loop for the same reason.
+    f32x4 la0, lb0, ea0, eb0, la1, lb1, ea1, eb1;
+    int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
+    {
+        const int64_t g0 = row_of(tile < n_tiles ? tile : 0);
+        fetch(LE + g0 * ldLE, Es + g0 * ldE, 0, la0, lb0, ea0, eb0);
+        fetch(LE + g0 * ldLE, Es + g0 * ldE, last < 1 ? last : 1, la1, lb1, ea1, eb1);
+    }
+    for (; tile < n_tiles; tile += tile_step) {
         const int64_t row0 = tile * 32;
-        int64_t grow_l = row0 + li;
-        grow_l = grow_l < n_rows ? grow_l : n_rows - 1;          // rows past the end re-read the last row, never stored
+        const int64_t grow_l = row_of(tile);
         const float *le_row = LE + grow_l * ldLE, *e_row = Es + grow_l * ldE;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        // the lane's four 16-byte pieces of a chunk: LE and E at columns c*16 + lh*4 (a) and c*16 + 8 + lh*4 (b); columns past
-        // d_in are re-read from the row's last float4 and zeroed
-        auto fetch = [&](int c, f32x4 &la, f32x4 &lb, f32x4 &ea, f32x4 &eb) {
-            const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
-            const int cca = ca < d4 ? ca : d4 - 4, ccb = cb < d4 ? cb : d4 - 4;
-            la = *reinterpret_cast<const f32x4 *>(le_row + cca);
-            ea = *reinterpret_cast<const f32x4 *>(e_row + cca);
-            lb = *reinterpret_cast<const f32x4 *>(le_row + ccb);
-            eb = *reinterpret_cast<const f32x4 *>(e_row + ccb);
-        };
         // sums and products of a chunk from its raw pieces; the zeroing of the columns past d_in happens HERE, at use - in
         // fetch() it would make the loads wait right where they are issued
         auto form = [&](int c, f32x4 la, f32x4 lb, f32x4 ea, f32x4 eb, f32x4 (&a4)[4]) {
@@ -392,15 +413,6 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
             }
             a4[0] = la + ea, a4[1] = lb + eb, a4[2] = la * ea, a4[3] = lb * eb;   // k-blocks: sum 0-7, sum 8-15, product 0-7, product 8-15
         };
-        // Two chunks of look-ahead in two fixed register sets (no rotation copies - a copy of a register that is still being
-        // loaded is a wait): the sums and products of a chunk are formed first, which frees its set for the chunk after next.
-        // Every prefetch is UNCONDITIONAL (past the end the last chunk is read again and never used): behind a branch the
-        // compiler cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) at the next use - the
-        // look-ahead then exists in the source only.  The odd last chunk is peeled off the loop for the same reason.
-        const int last = n_chunks - 1;
-        f32x4 la0, lb0, ea0, eb0, la1, lb1, ea1, eb1;
-        fetch(0, la0, lb0, ea0, eb0);
-        fetch(last < 1 ? last : 1, la1, lb1, ea1, eb1);
         auto chunk_mfma = [&](int c, const f32x4 (&a4)[4]) {
             const float *wc = W + (int64_t)c * NGCF_KC * WCOLS;
 #pragma unroll
@@ -420,14 +432,14 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
             {
                 f32x4 a4[4];
                 form(c, la0, lb0, ea0, eb0, a4);
-                fetch(c + 2 < last ? c + 2 : last, la0, lb0, ea0, eb0);               // in flight under two chunks of MFMAs
+                fetch(le_row, e_row, c + 2 < last ? c + 2 : last, la0, lb0, ea0, eb0);   // in flight under two chunks of MFMAs
                 __builtin_amdgcn_sched_barrier(0);      // (left alone the compiler sinks these loads to just before their use)
                 chunk_mfma(c, a4);
             }
             {
                 f32x4 a4[4];
                 form(c + 1, la1, lb1, ea1, eb1, a4);
-                fetch(c + 3 < last ? c + 3 : last, la1, lb1, ea1, eb1);
+                fetch(le_row, e_row, c + 3 < last ? c + 3 : last, la1, lb1, ea1, eb1);
                 __builtin_amdgcn_sched_barrier(0);
                 chunk_mfma(c + 1, a4);
             }
@@ -436,6 +448,12 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
             f32x4 a4[4];
             form(c, la0, lb0, ea0, eb0, a4);
             chunk_mfma(c, a4);
+        }
+        {   // the next tile's first two chunks, ahead of this tile's stores (the last tile of a wave re-reads its own)
+            const int64_t gn = row_of(tile + tile_step < n_tiles ? tile + tile_step : tile);
+            fetch(LE + gn * ldLE, Es + gn * ldE, 0, la0, lb0, ea0, eb0);
+            fetch(LE + gn * ldLE, Es + gn * ldE, last < 1 ? last : 1, la1, lb1, ea1, eb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue (wave-local): bias, LeakyReLU, dropout, row norm, stores
         const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
