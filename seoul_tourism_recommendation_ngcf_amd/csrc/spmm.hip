@@ -434,7 +434,11 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     if (!c || !E || !out) return fail(NGCF_ERR_ARG, "spmm: null argument");
     if (d <= 0 || d > 8192) return fail(NGCF_ERR_ARG, "spmm: width d=%d not in [1, 8192]", d);
     if (ldE < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm: leading dimension smaller than d");
-    if (d > 512) {   // wider than one wave covers: column panels of 512 (Seoul's 515-wide first layer, BASELINE configs[1])
+    // wider than one wave covers: column panels of 512.  Up to 768 aligned columns still run in one piece (three float4 per
+    // lane): Seoul's 515-wide first layer (BASELINE configs[1]) is 516 padded columns, and a 4-column panel of its own is four
+    // more launches on a launch-bound graph
+    const bool one_piece = d <= 768 && d % 4 == 0 && ldE % 4 == 0 && ldo % 4 == 0 && aligned16(E) && aligned16(out);
+    if (d > 512 && !one_piece) {
         for (int o = 0; o < d; o += 512) {
             const int rc = spmm_dispatch(c, E + o, ldE, std::min(512, d - o), out + o, ldo, workspace, workspace_bytes, stream, dr);
             if (rc != NGCF_OK) return rc;
@@ -505,7 +509,8 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
         else if (nq <= 16) rc = launch_spmm<4, 16, 1, 8>(a);
         else if (nq <= 32) rc = launch_spmm<4, 32, 1, 8>(a);
         else if (nq <= 64) rc = launch_spmm<4, 64, 1, 8>(a);
-        else rc = launch_spmm<4, 64, 2, 4>(a);
+        else if (nq <= 128) rc = launch_spmm<4, 64, 2, 4>(a);
+        else rc = launch_spmm<4, 64, 3, 2>(a);
     } else if (d <= 8) rc = launch_spmm<1, 8, 1, 8>(a);       // narrow tail panels: 8 gathered rows per wave instruction
     else if (d <= 64) rc = launch_spmm<1, 64, 1, 8>(a);
     else if (d <= 128) rc = launch_spmm<1, 64, 2, 4>(a);

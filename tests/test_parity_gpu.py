@@ -297,16 +297,18 @@ def test_default_segment_length_follows_the_matrix_size(dev, oracle_clib):
     rowptr[1:] = np.cumsum(lens)
     # the user rows gather from 100 table rows: their blocks run on the table-in-LDS kernel (spmm_ldstab_kernel), whole and
     # partial 64-float slices; mode 1 keeps everything on the plain row-wise kernel
-    for d in (64, 4, 96, 512, 200):
+    for d in (64, 4, 96, 512, 200, 516, 768, 772):
         E = rng.normal(0, 0.5, (N, d)).astype(np.float32)
         want = c_spmm(oracle_clib, rowptr, cols.astype(np.int32), vals, E)
         Ed = torch.from_numpy(E).to(dev)
         got = eng.spmm(csr, Ed).cpu().numpy()
-        np.testing.assert_allclose(got, want, atol=ATOL, rtol=RTOL)
+        # rows of ~4 400 terms of size ~0.15 summed in fp32, the oracle sequentially, the engine segment by segment: absolute
+        # tolerance for sums of that length (the error of either order against fp64 is ~3e-5 where the terms cancel)
+        np.testing.assert_allclose(got, want, atol=1e-4, rtol=RTOL)
         csr.set_mode(1)
         plain = eng.spmm(csr, Ed).cpu().numpy()
         csr.set_mode(0)
-        np.testing.assert_allclose(plain, want, atol=ATOL, rtol=RTOL)
+        np.testing.assert_allclose(plain, want, atol=1e-4, rtol=RTOL)
         np.testing.assert_allclose(got, plain, atol=2e-6, rtol=2e-5)
     small = eng.LaplacianCSR.from_coo(torch.from_numpy(rows[:5000]).to(dev), torch.from_numpy(cols[:5000]).to(dev),
                                       torch.from_numpy(vals[:5000]).to(dev), N, N)
