@@ -354,6 +354,45 @@ struct SpmmArgs {
     EdgeDrop dr;
 };
 
+// While the caller's stream is being CAPTURED into a hipGraph (GraphedForward on the launch-bound Seoul-sized graphs), the two
+// halves of a row-wise product - the segments of the long rows with their fix-up, and the kernels of the short rows - are
+// recorded as parallel branches (fork / join through a second stream): they write disjoint rows and are bound by different
+// things (L2 gathers / LDS).  Outside a capture nothing changes: in an eager step the extra event calls would cost more host
+// time than the overlap saves.  The stream and events are created on an eager call (GraphedForward warms up before capturing).
+struct ForkState {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int device = -1;
+};
+static ForkState g_fork;
+
+static bool fork_ready(hipStream_t stream)
+{
+    if (getenv("NGCF_NO_FORK")) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (st != hipStreamCaptureStatusActive) {
+        if (!g_fork.side) {
+            ForkState f;
+            if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming) == hipSuccess) {
+                f.device = dev;
+                g_fork = f;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        return false;
+    }
+    return g_fork.side != nullptr && g_fork.device == dev;
+}
+
 template <int VEC, int LPR, int CH, int U>
 int launch_spmm(const SpmmArgs &a)
 {
@@ -370,6 +409,22 @@ int launch_spmm(const SpmmArgs &a)
     // table-in-LDS kernel for the groups that gather from a few hundred rows: 16-byte pieces of 64-float slices
     const bool can_ldstab = VEC == 4 && a.d % 4 == 0 && c->mode != 1 && !getenv("NGCF_NO_LDSTAB");
     bool seg_done = seg_blocks == 0;
+    // under capture: segments (+ fix-up at the end) on the caller's stream, every group kernel on the side stream
+    // (only where the halves are long enough to be worth a dependency edge: Seoul-shaped C2, d = 512: 0.410 -> 0.385 ms per
+    // forward; C1, d = 64: 0.121 -> 0.132 ms, so not there)
+    const bool fork = seg_blocks > 0 && !a.with_swept && !c->groups.empty() && c->nnz * (int64_t)a.d >= 200000000 &&
+                      fork_ready(a.stream);
+    hipStream_t gs = a.stream;
+    if (fork) {
+        HIP_TRY(hipEventRecord(g_fork.ev_fork, a.stream));
+        HIP_TRY(hipStreamWaitEvent(g_fork.side, g_fork.ev_fork, 0));
+        gs = g_fork.side;
+        spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)seg_blocks), 256, 0, a.stream>>>(
+            c->rowptr, c->colidx, c->vals, 0, 0, seg_row, seg_begin, n_seg, seg_blocks, c->seg_len, a.E, a.ldE, a.d, a.out, a.ldo,
+            a.partial, a.dp, a.dr);
+        LAUNCH_CHECK();
+        seg_done = true;
+    }
     for (size_t g = 0; g <= c->groups.size(); ++g) {
         const bool last = g == c->groups.size();
         if (last && seg_done) break;
@@ -389,7 +444,7 @@ int launch_spmm(const SpmmArgs &a)
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsTableRows + 1) * 256));
                 attr_set = true;
             }
-            spmm_ldstab_kernel<4><<<dim3((unsigned)rb, (unsigned)n_slices), kLdsTabWaves * 64, lds, a.stream>>>(
+            spmm_ldstab_kernel<4><<<dim3((unsigned)rb, (unsigned)n_slices), kLdsTabWaves * 64, lds, gs>>>(
                 c->rowptr, c->colidx, c->vals, grp.begin, grp.end, (int)rpw, c->seg_len, a.E, a.ldE, a.d, grp.col_lo, n_tab, a.out,
                 a.ldo, a.dr);
             LAUNCH_CHECK();
@@ -399,7 +454,7 @@ int launch_spmm(const SpmmArgs &a)
             const int64_t rb = (c->groups[g].end - c->groups[g].begin + 3) / 4;
             const int64_t blocks = rb * (a.d / 32);
             if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
-            spmm_sliced_kernel<8><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(c->rowptr, c->colidx, c->vals, c->groups[g].begin,
+            spmm_sliced_kernel<8><<<dim3((unsigned)blocks), 256, 0, gs>>>(c->rowptr, c->colidx, c->vals, c->groups[g].begin,
                                                                                c->groups[g].end, rb, c->seg_len, a.E, a.ldE,
                                                                                a.out, a.ldo, a.dr);
             LAUNCH_CHECK();
@@ -411,7 +466,7 @@ int launch_spmm(const SpmmArgs &a)
         const int64_t blocks = sb + (rend - rbeg + 3) / 4;
         if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
         if (blocks > 0) {
-            spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, a.stream>>>(
+            spmm_kernel<VEC, LPR, CH, U><<<dim3((unsigned)blocks), 256, 0, gs>>>(
                 c->rowptr, c->colidx, c->vals, rbeg, rend, seg_row, seg_begin, seg_done ? 0 : n_seg, sb, c->seg_len,
                 a.E, a.ldE, a.d, a.out, a.ldo, a.partial, a.dp, a.dr);
             LAUNCH_CHECK();
@@ -423,6 +478,10 @@ int launch_spmm(const SpmmArgs &a)
         spmm_fixup_kernel<VEC><<<dim3((unsigned)fb), 256, 0, a.stream>>>(heavy_row, heavy_seg_ptr, n_heavy, a.partial, a.dp, a.d, a.out,
                                                                           a.ldo);
         LAUNCH_CHECK();
+    }
+    if (fork) {     // join: whatever follows on the caller's stream also follows the group kernels
+        HIP_TRY(hipEventRecord(g_fork.ev_join, g_fork.side));
+        HIP_TRY(hipStreamWaitEvent(a.stream, g_fork.ev_join, 0));
     }
     return NGCF_OK;
 }
