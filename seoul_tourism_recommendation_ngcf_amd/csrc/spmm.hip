@@ -450,7 +450,8 @@ int launch_spmm(const SpmmArgs &a)
             LAUNCH_CHECK();
             continue;
         }
-        if (!last && can_slice && c->groups[g].sliceable) {
+        // (a group of a few hundred rows is not worth a launch of its own: it rides with the segments below)
+        if (!last && can_slice && c->groups[g].sliceable && c->groups[g].end - c->groups[g].begin >= 1024) {
             const int64_t rb = (c->groups[g].end - c->groups[g].begin + 3) / 4;
             const int64_t blocks = rb * (a.d / 32);
             if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
