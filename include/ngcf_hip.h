@@ -247,11 +247,13 @@ int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ld
 /* weight gradients of one layer on the fp32 matrix cores: gW [d_out, 2 d_in] row-major,
  * gW[:, :d_in] = dM^T . (LE + E) (W1, NGCF.py:131-133), gW[:, d_in:] = dM^T . (LE * E) (W2, NGCF.py:135-136);
  * d_in, d_out <= 128 per call (the host tiles wider layers over column blocks of dM, LE and E).  Fixed
- * summation order (per-workgroup partials in the workspace, added in workgroup order). */
+ * summation order (per-workgroup partials in the workspace, added in workgroup order).
+ * gb (may be NULL): [d_out] column sums of dM from the same pass - the bias gradient of W2's bias, and half that of W1's
+ * (b1 enters the layer twice, NGCF.py:131,133). */
 int64_t ngcf_bwd_weight_workspace_bytes(void);
 int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
-                              int64_t n_rows, int d_in, int d_out, float *gW, void *workspace, int64_t workspace_bytes,
-                              void *stream);
+                              int64_t n_rows, int d_in, int d_out, float *gW, float *gb, void *workspace,
+                              int64_t workspace_bytes, void *stream);
 int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
                                int64_t n_rows, int d, float *dLE, int64_t ld_dLE, float *dE, int64_t ld_dE, void *stream);
 /* out[r, 0:d] += add[r, 0:d] */

@@ -68,7 +68,7 @@ PROTOTYPES = {
     "ngcf_sp_concat_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp]),
     "ngcf_layer_bwd_combine_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_bwd_weight_workspace_bytes": (_i64, []),
-    "ngcf_layer_bwd_weight_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp, _i64, _vp]),
+    "ngcf_layer_bwd_weight_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _i64, _vp]),
     "ngcf_add_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_topk_rows_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp]),
     "ngcf_recommend_topk_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),

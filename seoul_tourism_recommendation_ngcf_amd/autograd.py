@@ -113,12 +113,14 @@ def _sp_concat(LE, E):
 
 
 def _bwd_weight(dM, LE, E, ws):
-    """gW [d_out, 2 d_in] = dM^T . [LE+E | LE*E] on the fp32 matrix cores (ngcf_layer_bwd_weight_f32), in blocks of
-    at most 128 output rows x 128 input columns (one kernel call each)."""
+    """gW [d_out, 2 d_in] = dM^T . [LE+E | LE*E] on the fp32 matrix cores and gb [d_out] = column sums of dM (the bias
+    gradient) from the same pass over dM (ngcf_layer_bwd_weight_f32), in blocks of at most 128 output rows x 128 input
+    columns (one kernel call each)."""
     lib = _lib.load()
     n_rows, d_out = dM.shape
     d_in = int(LE.shape[1])
     gW = torch.empty((d_out, 2 * d_in), dtype=torch.float32, device=dM.device)
+    gb = torch.empty((d_out,), dtype=torch.float32, device=dM.device)
     nb = int(lib.ngcf_bwd_weight_workspace_bytes())
     w = ws.get(nb, dM.device)
     with torch.cuda.device(dM.device):
@@ -131,11 +133,11 @@ def _bwd_weight(dM, LE, E, ws):
                 a, b, c = dM[:, o0:o1], LE[:, c0:c1], E[:, c0:c1]
                 _lib.check(lib.ngcf_layer_bwd_weight_f32(_ptr(a), _row_major_ld(a, "dM"), _ptr(b), _row_major_ld(b, "LE"),
                                                          _ptr(c), _row_major_ld(c, "E"), n_rows, c1 - c0, o1 - o0, _ptr(blk),
-                                                         _ptr(w), w.numel(), _stream()))
+                                                         _ptr(gb[o0:o1]) if c0 == 0 else None, _ptr(w), w.numel(), _stream()))
                 if not whole:
                     gW[o0:o1, c0:c1] = blk[:, :c1 - c0]
                     gW[o0:o1, d_in + c0:d_in + c1] = blk[:, c1 - c0:]
-    return gW
+    return gW, gb
 
 
 def _bwd_combine(dSP, LE, E):
@@ -238,9 +240,8 @@ class Propagate(torch.autograd.Function):
                 dM = _bwd_pre(g_all[rows, offs[k]:offs[k] + d_out], None, C_k[rows], _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
                               None if mask_k is None else mask_k[rows], rows)
                 LE_c, E_c = LE_k[rows], E_k[rows]
-                gW = _bwd_weight(dM, LE_c, E_c, ws)
+                gW, gb = _bwd_weight(dM, LE_c, E_c, ws)
                 gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
-                gb = dM.sum(0)
                 gb1[k], gb2[k] = 2.0 * gb, gb
                 if d_out % 4 == 0 and d_out >= 4:
                     dLE_c, dE_c = _bwd_input(dM, w1[k], w2[k], LE_c, E_c, ws)
@@ -254,9 +255,8 @@ class Propagate(torch.autograd.Function):
                 dC = dE
                 continue
             dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k], mask_k)
-            gW = _bwd_weight(dM, LE_k, E_k, ws)                                  # MFMA kernel, operand formed on the fly
+            gW, gb = _bwd_weight(dM, LE_k, E_k, ws)                              # MFMA kernel, operand formed on the fly; bias too
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
-            gb = dM.sum(0)
             gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
             if d_out % 4 == 0 and d_out >= 4:                                    # dM rows are contiguous [N, d_out]: 16-byte aligned
                 dLE, dE = _bwd_input(dM, w1[k], w2[k], LE_k, E_k, ws)             # one MFMA kernel, dS/dP never stored

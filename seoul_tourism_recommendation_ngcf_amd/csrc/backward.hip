@@ -234,7 +234,8 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict__ dM, int64_t ldM,
                                                          const float *__restrict__ LE, int64_t ldLE,
                                                          const float *__restrict__ E, int64_t ldE, int64_t n_rows, int d_in,
-                                                         int d_out, int P, float *__restrict__ partial)
+                                                         int d_out, int P, float *__restrict__ partial,
+                                                         float *__restrict__ partial_bias)
 {
     __shared__ float As[2][kBwRows][kBwM];     // dM rows, columns >= d_out stay zero
     __shared__ float Bs[2][kBwRows][kBwN];     // [LE+E (P columns) | LE*E (P columns)], the rest stays zero
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
     // staging: 2 float4 slots per thread and operand: slot s -> row s / 32, columns 4 * (s % 32) ..
     bw_f32x4 rm[2], rl[2], re[2];
     const int64_t n_blocks = (n_rows + kBwRows - 1) / kBwRows;
@@ -296,6 +298,10 @@ __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict
     for (; b < n_blocks; b += gridDim.x, buf ^= 1) {
         const bool more = b + gridDim.x < n_blocks;
         if (more) load_block(b + gridDim.x);   // the next block's global loads fly under the MFMAs
+        // bias gradient = column sums of dM (NGCF.py:131-136: b1 enters twice, b2 once - the caller scales): thread (o, q)
+        // adds rows 8 q .. 8 q + 7 of column o of the block that is in LDS anyway
+#pragma unroll
+        for (int r = 0; r < kBwRows / 4; ++r) bsum += As[buf][(tid >> 7) * (kBwRows / 4) + r][tid & (kBwM - 1)];
 #pragma unroll
         for (int j = 0; j < kBwRows / 2; ++j) {
             const float bv = Bs[buf][2 * j + lh][wave * 32 + li];
@@ -314,13 +320,26 @@ __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict
             const int o = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             out[o * kBwN + wave * 32 + li] = acc[t][r];
         }
+    // the four row-quarters of a column, added in a fixed order (the last loop iteration ended with a barrier: As is free)
+    float *bs = &As[0][0][0];
+    bs[tid] = bsum;
+    __syncthreads();
+    if (tid < kBwM) partial_bias[(int64_t)blockIdx.x * kBwM + tid] = ((bs[tid] + bs[kBwM + tid]) + bs[2 * kBwM + tid]) + bs[3 * kBwM + tid];
 }
 
-__global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, int n_wg, int d_in, int d_out, int P,
-                                         float *__restrict__ gW)
+__global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ partial_bias, int n_wg, int d_in,
+                                         int d_out, int P, float *__restrict__ gW, float *__restrict__ gb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d_out * 2 * d_in) return;
+    if (i >= d_out * 2 * d_in) {
+        const int o = i - d_out * 2 * d_in;
+        if (gb && o < d_out) {
+            float s = 0.f;
+            for (int w = 0; w < n_wg; ++w) s += partial_bias[(int64_t)w * kBwM + o];
+            gb[o] = s;
+        }
+        return;
+    }
     const int o = i / (2 * d_in), c = i % (2 * d_in);
     const int src = c < d_in ? c : P + (c - d_in);
     float s = 0.f;
@@ -328,10 +347,13 @@ __global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, int 
     gW[i] = s;
 }
 
-extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void) { return (int64_t)kBwWGs * kBwM * kBwN * sizeof(float) + 256; }
+extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void)
+{
+    return (int64_t)kBwWGs * kBwM * kBwN * sizeof(float) + (int64_t)kBwWGs * kBwM * sizeof(float) + 256;
+}
 
 extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E,
-                                         int64_t ldE, int64_t n_rows, int d_in, int d_out, float *gW, void *workspace,
+                                         int64_t ldE, int64_t n_rows, int d_in, int d_out, float *gW, float *gb, void *workspace,
                                          int64_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -343,15 +365,16 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
         return fail(NGCF_ERR_WORKSPACE, "layer_bwd_weight: workspace %lld B < %lld B", (long long)workspace_bytes,
                     (long long)ngcf_bwd_weight_workspace_bytes());
     float *partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    float *partial_bias = partial + (int64_t)kBwWGs * kBwM * kBwN;
     const int P = (int)align_up(d_in, 32);
     const bool al = ldM % 4 == 0 && ldLE % 4 == 0 && ldE % 4 == 0 && aligned16(dM) && aligned16(LE) && aligned16(E);
     if (al)
-        bwd_weight_kernel<true><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial);
+        bwd_weight_kernel<true><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     else
-        bwd_weight_kernel<false><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial);
+        bwd_weight_kernel<false><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     LAUNCH_CHECK();
-    const int total = d_out * 2 * d_in;
-    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, kBwWGs, d_in, d_out, P, gW);
+    const int total = d_out * 2 * d_in + (gb ? d_out : 0);
+    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, partial_bias, kBwWGs, d_in, d_out, P, gW, gb);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

@@ -142,7 +142,7 @@ def test_bpr_backward_matches_golden_grads(dev):
                                                         (9001, 128, 128, False), (70000, 130 - 2, 96, True), (3000, 130, 200, False),
                                                         (777, 515, 64, True)])
 def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
-    """gW = dM^T . [LE+E | LE*E] (MFMA kernel, csrc/backward.hip) against fp64 from the definition (NGCF.py:131-136),
+    """gW = dM^T . [LE+E | LE*E] and gb = column sums of dM (MFMA kernel, csrc/backward.hip) against fp64 from the definition (NGCF.py:131-136),
     incl. widths that are not multiples of 32 or 4, a row count that is not a multiple of the block, strided operands
     and the empty case.  Summation order differs from any reference GEMM: tolerance, relative to the result's scale."""
     from seoul_tourism_recommendation_ngcf_amd import autograd, engine
@@ -150,13 +150,17 @@ def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
     mk = lambda n, d: torch.randn((n, d + (12 if strided else 0)), generator=g, device=dev)[:, :d]  # noqa: E731
     dM, LE, E = mk(n_rows, d_out), mk(n_rows, d_in), mk(n_rows, d_in)
     ws = engine.Workspace()
-    got = autograd._bwd_weight(dM, LE, E, ws)
-    assert got.shape == (d_out, 2 * d_in)
+    got, gb = autograd._bwd_weight(dM, LE, E, ws)
+    assert got.shape == (d_out, 2 * d_in) and gb.shape == (d_out,)
     SP = torch.cat([LE.double() + E.double(), LE.double() * E.double()], 1)
     want = dM.double().t() @ SP
     scale = max(float(want.abs().max()), 1.0) if n_rows else 1.0
     assert float((got.double() - want).abs().max()) <= 2e-5 * scale
-    assert torch.equal(got, autograd._bwd_weight(dM, LE, E, ws))        # fixed summation order
+    # the bias gradient (column sums of dM) from the same pass
+    want_b = dM.double().sum(0)
+    assert float((gb.double() - want_b).abs().max()) <= 2e-5 * max(float(want_b.abs().max()), 1.0)
+    again, gb2 = autograd._bwd_weight(dM, LE, E, ws)
+    assert torch.equal(got, again) and torch.equal(gb, gb2)             # fixed summation order
 
 
 @pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(1, 4, 4, False), (130, 128, 128, False), (1000, 130, 128, True), (333, 65, 64, True),
