@@ -184,10 +184,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
+        import datetime
+        to = datetime.timedelta(minutes=5)             # a rank that dies must not leave the others waiting for the default half hour
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=to)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=to)
 
     import seoul_tourism_recommendation_ngcf_amd as pkg
     from seoul_tourism_recommendation_ngcf_amd import _lib, dist as ngcf_dist
