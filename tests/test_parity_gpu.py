@@ -922,3 +922,38 @@ def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, 
         m = (le + e) @ W1.double().T + b1.double() + (le * e) @ W2.double().T + b2.double() + b1.double()
         m = torch.nn.functional.leaky_relu(m, 0.2)
         torch.testing.assert_close(outs[0][0][:32].double(), m, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n_rows,n_tab,deg,d", [(1, 1, 1, 4), (63, 7, 3, 60), (65, 100, 50, 64), (5000, 511, 200, 68),
+                                               (70000, 512, 20, 128), (300, 100, 700, 516), (2000, 64, 0, 64),
+                                               (4097, 300, 130, 200)])
+def test_table_in_lds_kernel_shapes(n_rows, n_tab, deg, d, dev, oracle_clib):
+    """spmm_ldstab_kernel at its edges: one table row and the 512-row limit (131 KB of LDS), rows of 0 / 1 / 64 < n <= 128 / more
+    than 128 entries (the third-batch path) and rows longer than the segment length inside the group (left to the segment
+    kernels), partial last slices, more rows than one workgroup block; the table sits in the MIDDLE of a wider column range
+    (col_lo > 0).  Against the C oracle and the plain row-wise kernels."""
+    eng = _pkg().engine
+    rng = np.random.default_rng(n_rows * 7 + n_tab)
+    n_cols, col_lo = 3 * n_tab + 11, n_tab + 5
+    lens = rng.poisson(deg, n_rows) if deg else np.zeros(n_rows, np.int64)
+    if n_rows > 10 and deg:
+        lens[3], lens[n_rows // 2] = 0, 3 * max(deg, 100)              # an empty row and a long one
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    nnz = int(rowptr[-1])
+    cols = (col_lo + rng.integers(0, n_tab, nnz)).astype(np.int64)
+    vals = rng.normal(0, 0.3, nnz).astype(np.float32)
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), lens)
+    if nnz == 0:
+        rows, cols, vals = np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32)
+    csr = eng.LaplacianCSR.from_coo(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev), torch.from_numpy(vals).to(dev),
+                                    n_rows, n_cols)
+    E = rng.normal(0, 0.5, (n_cols, d)).astype(np.float32)
+    Ed = torch.from_numpy(E).to(dev)
+    want = c_spmm(oracle_clib, rowptr, cols.astype(np.int32), vals, E)
+    got = eng.spmm(csr, Ed).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=RTOL)
+    csr.set_mode(1)
+    plain = eng.spmm(csr, Ed).cpu().numpy()
+    np.testing.assert_allclose(got, plain, atol=5e-6, rtol=2e-5)
+    assert np.all(got[lens == 0] == 0)
