@@ -112,15 +112,15 @@ int ngcf_spmm_csr_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d,
 
 /*
  * LE = drop(L).E with node dropout on the device (NGCF.py:93-100,124-126 semantics: every stored entry is kept
- * with probability 1-p, values are NOT rescaled, and the thinning is cumulative over layers): entry e survives
- * iff hash(seeds[j], e) passes for every j < n_seeds (layer k passes its own and all earlier layers' seeds,
- * n_seeds <= 4, host array).  No CSR is rebuilt; dropped entries are compacted away inside each wave.
- * `eid` (device int64[nnz], may be NULL) gives, for a transposed CSR, the entry number in L of each stored entry,
- * so that L^T is thinned consistently in the backward pass.  The mask is a counter-based hash, not torch's
- * generator: same distribution as the reference, different stream.
+ * with probability 1-p, values are NOT rescaled, and the thinning is cumulative over layers): the entry (i, j) of L
+ * survives iff hash(seeds[q], i, j) passes for every q < n_seeds (layer k passes its own and all earlier layers' seeds,
+ * n_seeds <= 4, host array).  No CSR is rebuilt.  The hash is keyed by the entry's row and column in L, so any layout of
+ * L is thinned the same way: pass `transposed` != 0 when `csr` holds L^T (the backward pass), and L^T loses exactly the
+ * entries L lost.  (Entries stored twice at the same (i, j) share their fate.)  The mask is a counter-based hash, not
+ * torch's generator: same distribution as the reference, different stream.
  */
 int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
-                              float drop_p, const uint64_t *seeds, int n_seeds, const int64_t *eid,
+                              float drop_p, const uint64_t *seeds, int n_seeds, int transposed,
                               void *workspace, int64_t workspace_bytes, void *stream);
 
 /*

@@ -159,12 +159,10 @@ class NGCF(nn.Module):
         return csr
 
     def _transposed_csr(self, idx: torch.Tensor, val: torch.Tensor) -> "_eng.LaplacianCSR":
-        """CSR of the transpose; `.eid[j]` is the entry number in the untransposed matrix of its j-th entry."""
+        """CSR of the transpose (the device-mode edge dropout is keyed by (row, column) of L: no entry map is needed)."""
         N = self.n_user + self.n_item
         order = torch.sort(idx[1], stable=True).indices          # by column = row of L^T, original order kept inside
-        csr = _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N)
-        csr.eid = order.contiguous()
-        return csr
+        return _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N)
 
     def _layer_params(self):
         return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],

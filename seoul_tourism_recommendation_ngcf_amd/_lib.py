@@ -43,7 +43,7 @@ PROTOTYPES = {
     "ngcf_layer_workspace_bytes": (_i64, [_vp, C.c_int, C.c_int]),
     "ngcf_dense_workspace_bytes": (_i64, [C.c_int, C.c_int]),
     "ngcf_spmm_csr_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
-    "ngcf_spmm_csr_dropout_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, _vp,
+    "ngcf_spmm_csr_dropout_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, C.c_int,
                                             _vp, _i64, _vp]),
     "ngcf_layer_fused_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
                                        _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -78,7 +78,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
             _eng.layer_fused(csrs[k], prev, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(),
                              carry, all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k], mk)
         else:   # device-side node dropout: thinned SpMM, then the dense half
-            LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=(edge_drops[k][0], edge_drops[k][1], None))
+            LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=(edge_drops[k][0], edge_drops[k][1], False))
             _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
                              all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k], mk)
         prev = carry
@@ -193,7 +193,7 @@ class Propagate(torch.autograd.Function):
         ins, les, carries = [], [], []
         for k in range(n_layer):
             d_out = widths[k + 1]
-            ed = None if edge_drops is None else (edge_drops[k][0], edge_drops[k][1], None)
+            ed = None if edge_drops is None else (edge_drops[k][0], edge_drops[k][1], False)
             LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=ed)        # saved for the backward
             carry = torch.empty((N, d_out), dtype=torch.float32, device=dev)
             _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
@@ -265,7 +265,7 @@ class Propagate(torch.autograd.Function):
                 dLE, dE = _bwd_combine(dSP, LE_k, E_k)
                 del dSP
             del dM
-            ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], ctx.csrs_t[k].eid)
+            ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], True)
             _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed))     # dE += (thinned L)^T . dLE
             dC = dE
         dE0 = dC

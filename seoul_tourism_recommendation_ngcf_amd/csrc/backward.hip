@@ -581,12 +581,7 @@ __global__ __launch_bounds__(256) void spmm_scatter_rows_kernel(const int64_t *_
         if (lane < cnt) {
             c = colidx[base + lane];
             v = vals[base + lane];
-            if (dr.n > 0) {                                  // device-side node dropout: the same keep test as the forward SpMM
-                const uint64_t e = (uint64_t)(dr.eid ? dr.eid[base + lane] : base + lane) * 0x9E3779B97F4A7C15ULL;
-                bool keep = true;
-                for (int q = 0; q < dr.n; ++q) keep = keep && mix32(dr.seed[q] ^ e) >= dr.thr;
-                v = keep ? v : 0.f;
-            }
+            if (dr.n > 0) v = edge_keep(dr, row, c) ? v : 0.f;   // device-side node dropout: the same keep test as the forward SpMM
         }
         for (int j = 0; j < cnt; ++j) {
             const int cj = __shfl(c, j);
@@ -608,7 +603,7 @@ extern "C" int ngcf_spmm_scatter_rows_f32(const ngcf_csr_t *c, const int64_t *ro
     if (n_sel == 0 || max_row_len <= 0) return NGCF_OK;
     if (!rows || !X || !out || d <= 0 || d > 512 || ldx < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: bad argument (d <= 512)");
     if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: 0..4 seeds expected");
-    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, nullptr};
+    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, 0};
     for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
     const int64_t segs = (max_row_len + kScatSeg - 1) / kScatSeg;
     if (n_sel >= (int64_t)1 << 31 || segs > 65535) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: too many rows / too long a row");

@@ -150,18 +150,29 @@ __device__ inline uint32_t mix32(uint64_t x)
 }
 
 // Device-side node dropout (NGCF.py:93-100 semantics: keep each stored entry w.p. 1-p, values NOT rescaled,
-// cumulative over layers): entry e survives layer k iff mix32(seed_j ^ e*K) >= thr for every j <= k.
-// `eid` maps the entries of a transposed CSR back to the entry numbers of L (NULL: the entry position itself).
+// cumulative over layers): the entry (i, j) of L survives layer k iff mix32(seed_q ^ key(i, j)) >= thr for every q <= k.
+// The key is the entry's (row, column) in L - not its position in some storage order - so every kernel that walks L in
+// whatever layout (row-wise CSR, the L2-swept plan, the rows of L^T, a scatter over selected rows) thins it the same way
+// without a map between layouts; `transposed` says that the CSR being walked is L^T (its rows are L's columns).
 struct EdgeDrop {
     int n;                  // number of seeds (0 = no dropout)
     uint32_t thr;           // p * 2^32
     uint64_t seed[4];
-    const int64_t *eid;
+    int transposed;
 };
+
+__device__ inline bool edge_keep(const EdgeDrop &dr, int64_t row, int64_t col)   // row, col of the CSR being walked
+{
+    const uint64_t i = (uint64_t)(dr.transposed ? col : row), j = (uint64_t)(dr.transposed ? row : col);
+    const uint64_t e = ((i << 32) | (j & 0xffffffffull)) * 0x9E3779B97F4A7C15ULL;
+    bool keep = true;
+    for (int q = 0; q < dr.n; ++q) keep = keep && mix32(dr.seed[q] ^ e) >= dr.thr;
+    return keep;
+}
 
 
 int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, void *workspace,
-                  int64_t workspace_bytes, hipStream_t stream, const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr});
+                  int64_t workspace_bytes, hipStream_t stream, const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, 0});
 // swept parts (spmm_swept.hip): kernels + fix-ups of every part; `partial` is the workspace base (rows of dp floats)
 int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, float *partial, int dp,
                  hipStream_t stream);

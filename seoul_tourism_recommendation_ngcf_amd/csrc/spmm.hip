@@ -17,17 +17,18 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
 {
     using V = typename VecT<VEC>::type;
     const int wave = threadIdx.x >> 6;
-    int64_t begin, end;
+    int64_t begin, end, row;
     float *dst;
     if ((int64_t)blockIdx.x < seg_blocks) {
         const int64_t s = (int64_t)blockIdx.x * 4 + wave;
         if (s >= n_seg) return;
         begin = seg_begin[s];
-        const int64_t row_end = rowptr[seg_row[s] + 1];
+        row = seg_row[s];
+        const int64_t row_end = rowptr[row + 1];
         end = begin + seg_len < row_end ? begin + seg_len : row_end;
         dst = partial + s * (int64_t)dp;
     } else {
-        const int64_t row = row_begin + ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
+        row = row_begin + ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
         if (row >= n_rows) return;
         begin = rowptr[row];
         end = rowptr[row + 1];
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
     V acc[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) acc[ch] = vzero<VEC>();
-    spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc, dr);
+    spmm_accumulate<VEC, LPR, CH, U>(colidx, vals, begin, end, E, ldE, d, acc, dr, 0, row);
     spmm_store<VEC, LPR, CH>(acc, dst, d);
 }
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
     if (end - begin > seg_len) return;   // cut row: produced from its segments
     float4 acc[1];
     acc[0] = vzero4();
-    spmm_accumulate<4, 8, 1, U>(colidx, vals, begin, end, E + slice * 32, ldE, 32, acc, dr);
+    spmm_accumulate<4, 8, 1, U>(colidx, vals, begin, end, E + slice * 32, ldE, 32, acc, dr, 0, row);
     spmm_store<4, 8, 1>(acc, out + row * ldo + slice * 32, 32);
 }
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kLdsTabWaves * 64) void spmm_ldstab_kernel(const in
             if (end - begin > seg_len) continue;       // cut row: produced from its segments
             float4 acc[1];
             acc[0] = vzero4();
-            spmm_accumulate<4, 16, 1, U>(colidx, vals, begin, end, tab, 64, 64, acc, dr, col_lo);
+            spmm_accumulate<4, 16, 1, U>(colidx, vals, begin, end, tab, 64, 64, acc, dr, col_lo, r0 + wave + (int64_t)k * kLdsTabWaves);
             store(k, acc[0]);
         }
         return;
@@ -587,12 +588,12 @@ extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ld
 }
 
 extern "C" int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,
-                                         float drop_p, const uint64_t *seeds, int n_seeds, const int64_t *eid,
+                                         float drop_p, const uint64_t *seeds, int n_seeds, int transposed,
                                          void *workspace, int64_t workspace_bytes, void *stream)
 {
     if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_dropout: 0..4 seeds expected");
     if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "spmm_dropout: drop_p=%f not in [0,1)", drop_p);
-    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, eid};
+    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, transposed ? 1 : 0};
     for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
     return spmm_dispatch(c, E, ldE, d, LE, ldLE, workspace, workspace_bytes, (hipStream_t)stream, dr);
 }

@@ -75,8 +75,8 @@ __device__ inline void spmm_combine(typename VecT<VEC>::type (&acc)[CH])
 template <int VEC, int LPR, int CH, int U>
 __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
                                        int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
-                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, nullptr},
-                                       int pad_col = 0)
+                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, 0},
+                                       int pad_col = 0, int64_t row = 0)     // row: the CSR row being walked (edge dropout key)
 {
     const int lane = threadIdx.x & 63;
     const int l = lane % LPR;
@@ -98,11 +98,7 @@ __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const
         }
         if (dr.n > 0) {
             // drop entries, then compact the survivors to the low lanes (dropped ones go to the top, unused)
-            bool keep = lane < cnt;
-            if (keep) {
-                const uint64_t e = (uint64_t)(dr.eid ? dr.eid[base + lane] : base + lane) * 0x9E3779B97F4A7C15ULL;
-                for (int q = 0; q < dr.n; ++q) keep = keep && mix32(dr.seed[q] ^ e) >= dr.thr;
-            }
+            const bool keep = lane < cnt && edge_keep(dr, row, c);
             const unsigned long long m = __ballot(keep);
             const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
             const int dst = keep ? __popcll(m & lt) : 63 - __popcll(~m & lt);

@@ -165,9 +165,9 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
          edge_drop=None):
     """LE = L.E (NGCF.py:130) through ngcf_spmm_csr_f32.
 
-    `edge_drop = (seeds, p, eid)` applies device-side node dropout (ngcf_spmm_csr_dropout_f32): `seeds` the
-    cumulative list of 64-bit layer seeds, `p` the drop probability, `eid` None or the int64 entry-number map of a
-    transposed CSR."""
+    `edge_drop = (seeds, p, transposed)` applies device-side node dropout (ngcf_spmm_csr_dropout_f32): `seeds` the
+    cumulative list of 64-bit layer seeds, `p` the drop probability, `transposed` true when `csr` holds L^T (the mask is
+    keyed by an entry's row and column in L, so L^T loses the entries L lost)."""
     lib = _lib.load()
     _f32c(E, "E")
     d = int(E.shape[1])
@@ -191,10 +191,10 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
             _lib.check(lib.ngcf_spmm_csr_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
                                              _row_major_ld(out, "out"), _ptr(w), w.numel(), _stream()))
         else:
-            seeds, p, eid = edge_drop
+            seeds, p, transposed = edge_drop
             arr = (C.c_uint64 * max(len(seeds), 1))(*[int(x) & (2 ** 64 - 1) for x in seeds])
             _lib.check(lib.ngcf_spmm_csr_dropout_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
-                                                     _row_major_ld(out, "out"), float(p), arr, len(seeds), _ptr(eid),
+                                                     _row_major_ld(out, "out"), float(p), arr, len(seeds), 1 if transposed else 0,
                                                      _ptr(w), w.numel(), _stream()))
     assert out.shape[1] == d_view
     return out

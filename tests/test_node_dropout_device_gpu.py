@@ -22,8 +22,11 @@ def mix32(x):
     return (x & np.uint64(0xFFFFFFFF)).astype(np.uint64)
 
 
-def keep_mask(nnz, seeds, p):
-    e = (np.arange(nnz, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & M64
+def keep_mask(rows, cols, seeds, p):
+    """The library's mask (csrc/common.h, edge_keep): keyed by the entry's (row, column) in L."""
+    key = (np.asarray(rows).astype(np.uint64) << np.uint64(32)) | (np.asarray(cols).astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    nnz = key.size
+    e = (key * np.uint64(0x9E3779B97F4A7C15)) & M64
     thr = np.uint64(int(p * 4294967296.0))
     keep = np.ones(nnz, bool)
     for s in seeds:
@@ -41,8 +44,8 @@ def test_dropout_spmm_matches_host_mask_and_statistics():
     X = torch.randn((N, 128), generator=torch.Generator(device=dev).manual_seed(1), device=dev)
     seeds, p = [12345, 987654321, 5], 0.3
     for n in (1, 2, 3):
-        got = eng.spmm(csr, X, edge_drop=(seeds[:n], p, None))
-        keep = torch.from_numpy(keep_mask(coo["nnz"], seeds[:n], p)).to(dev)
+        got = eng.spmm(csr, X, edge_drop=(seeds[:n], p, False))
+        keep = torch.from_numpy(keep_mask(coo["rows"].cpu().numpy(), coo["cols"].cpu().numpy(), seeds[:n], p)).to(dev)
         frac = float(keep.float().mean())
         assert abs(frac - (1 - p) ** n) < 0.005                       # cumulative thinning
         thin = eng.LaplacianCSR.from_coo(coo["rows"][keep], coo["cols"][keep], coo["vals"][keep], N, N)
@@ -80,7 +83,7 @@ def test_module_device_node_dropout_forward_and_gradients():
     E = torch.cat((uw, leaves["item_embedding.weight"]), 0)
     blocks = [E]
     for k in range(3):
-        keep = keep_mask(len(vals), seeds[:k + 1], float(g["meta"][5]))
+        keep = keep_mask(rows, cols, seeds[:k + 1], float(g["meta"][5]))
         Lk = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[keep], cols[keep]])), torch.from_numpy(vals[keep]), (N, N))
         LE = torch.mm(Lk, E)
         M = torch.nn.functional.linear(LE, w1[k], b1[k]) + torch.nn.functional.linear(E, w1[k], b1[k]) \
