@@ -107,6 +107,7 @@ struct ngcf_csr {
             int32_t *e_pack = nullptr;         // device [n_slots] (local row << 25) | column; negative: empty slot
             float *e_val = nullptr;            // device [n_slots]
             int32_t *dst = nullptr;            // device [n_tasks*rows_per_wave] >=0 output row, <=-2 the part's partial row -2-p, -1 unused
+            int32_t *prow = nullptr;           // device [n_tasks*rows_per_wave] the matrix row behind every accumulator row (cut rows too)
             int32_t *heavy_row = nullptr;      // device [n_heavy]   rows cut into pieces
             int64_t *heavy_seg_ptr = nullptr;  // device [n_heavy+1] their ranges of the part's partial rows
         };
@@ -175,7 +176,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
                   int64_t workspace_bytes, hipStream_t stream, const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, 0});
 // swept parts (spmm_swept.hip): kernels + fix-ups of every part; `partial` is the workspace base (rows of dp floats)
 int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, float *partial, int dp,
-                 hipStream_t stream);
+                 hipStream_t stream, const EdgeDrop &dr);
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers

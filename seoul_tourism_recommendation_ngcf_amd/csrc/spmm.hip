@@ -511,15 +511,15 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     const bool rows_aligned = (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
     // (measured at 130 on C3: 19.5 -> 18.7 ms per forward; with edge dropout the second pass over the entries costs
     // more than the scalar loads, so those products stay in one piece)
-    if (rows_aligned && d > 4 && dr.n == 0 && !getenv("NGCF_NO_PANEL_SPLIT")) {
+    if (rows_aligned && d > 4 && !getenv("NGCF_NO_PANEL_SPLIT")) {
         int main = 0;
         if (d % 64 != 0 && d > 64 && swept_usable(c, ldE, d & ~63)) main = d & ~63;                // swept kernel + tail
-        else if (d % 4 != 0) main = d & ~3;                                                        // float4 kernel + 1..3 columns
+        else if (d % 4 != 0 && dr.n == 0) main = d & ~3;                                           // float4 kernel + 1..3 columns
         if (main > 0) {
             const int rc = spmm_dispatch(c, E, ldE, main, out, ldo, workspace, workspace_bytes, stream, dr);
             if (rc != NGCF_OK) return rc;
             const int tail = d - main;
-            if (tail <= 4 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !getenv("NGCF_NO_TAIL_TABLE")) {
+            if (tail <= 4 && dr.n == 0 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !getenv("NGCF_NO_TAIL_TABLE")) {
                 // workspace: [partial sums ...            | T_in [n_cols] | T_out [n_rows]]
                 uintptr_t end = reinterpret_cast<uintptr_t>(workspace) + (uintptr_t)workspace_bytes;
                 float4 *Tout = reinterpret_cast<float4 *>((end - (uintptr_t)(c->n_rows * (int64_t)sizeof(float4))) & ~(uintptr_t)255);
@@ -551,7 +551,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     }
     const int dp = (int)align_up(d, 4);
     const bool vec = (d % 4 == 0) && rows_aligned;
-    const bool with_swept = vec && dr.n == 0 && swept_usable(c, ldE, d);
+    const bool with_swept = vec && swept_usable(c, ldE, d);               // (under edge dropout: the DROP instantiation)
     float *partial = nullptr;
     if (with_swept ? c->swept.out.n_seg + c->swept.n_partial > 0 : c->n_seg > 0) {
         const int64_t need = partial_bytes(c, d);
@@ -562,7 +562,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     SpmmArgs a{with_swept, c, E, ldE, d, out, ldo, partial, dp, stream, dr};
     prof_mark(stream, 0);                       // one L.E product = everything between the two marks
     int rc = NGCF_OK;
-    if (with_swept) rc = launch_swept(c, E, ldE, d, out, ldo, partial, dp, stream);
+    if (with_swept) rc = launch_swept(c, E, ldE, d, out, ldo, partial, dp, stream, dr);
     if (rc != NGCF_OK) return rc;
     if (vec) {
         const int nq = d / 4;

@@ -68,6 +68,7 @@ void free_part(ngcf_csr::Swept::Part &p)
     if (p.e_pack) (void)hipFree(p.e_pack);
     if (p.e_val) (void)hipFree(p.e_val);
     if (p.dst) (void)hipFree(p.dst);
+    if (p.prow) (void)hipFree(p.prow);
     if (p.heavy_row) (void)hipFree(p.heavy_row);
     if (p.heavy_seg_ptr) (void)hipFree(p.heavy_seg_ptr);
     p = ngcf_csr::Swept::Part();
@@ -96,6 +97,7 @@ struct Piece {
     int64_t row;            // >= 0 row of the part, < 0 partial row -1-p of the part
     int64_t begin, end, count;
     int32_t off, step;
+    int64_t src;            // the row of the part its entries come from (== row when the row is not cut)
 };
 
 // Plan of the rows [row_lo, row_hi).  Leaves part.waves == 0 when the part is not worth it (mode 3) or the shape does
@@ -150,11 +152,11 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
         for (int64_t r = 0; r < n; ++r) {
             const int64_t b = rp[(size_t)r], e = rp[(size_t)r + 1], len = e - b;
             if (len <= Tp) {
-                pieces.push_back({r, b, e, len, 0, 1});
+                pieces.push_back({r, b, e, len, 0, 1, r});
             } else {
                 const int64_t k = (len + Tp - 1) / Tp;
                 heavy_row.push_back((int32_t)(row_lo + r));
-                for (int64_t j = 0; j < k; ++j) pieces.push_back({-1 - n_partial++, b, e, (len - j + k - 1) / k, (int32_t)j, (int32_t)k});
+                for (int64_t j = 0; j < k; ++j) pieces.push_back({-1 - n_partial++, b, e, (len - j + k - 1) / k, (int32_t)j, (int32_t)k, r});
                 heavy_ptr.push_back(n_partial);
             }
         }
@@ -403,11 +405,12 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
             }
         }
     });
-    std::vector<int32_t> dst((size_t)(n_tasks * RW), -1);
+    std::vector<int32_t> dst((size_t)(n_tasks * RW), -1), prow((size_t)(n_tasks * RW), 0);
     for (size_t i = 0; i < dst.size(); ++i) {
         if (task_piece[i] < 0) continue;
         const int64_t r = pieces[(size_t)task_piece[i]].row;
         dst[i] = r >= 0 ? (int32_t)(row_lo + r) : (int32_t)(-2 - (-1 - r));
+        prow[i] = (int32_t)(row_lo + pieces[(size_t)task_piece[i]].src);   // the matrix row behind every accumulator row (edge dropout key)
     }
     if (getenv("NGCF_SWEPT_DEBUG")) {
         int64_t mx = 0, mn = INT64_MAX;
@@ -438,6 +441,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     if (rc == NGCF_OK) rc = upload(&part.e_pack, e_pack, stream);
     if (rc == NGCF_OK) rc = upload(&part.e_val, e_val, stream);
     if (rc == NGCF_OK) rc = upload(&part.dst, dst, stream);
+    if (rc == NGCF_OK) rc = upload(&part.prow, prow, stream);
     if (rc == NGCF_OK && part.n_heavy > 0) rc = upload(&part.heavy_row, heavy_row, stream);
     if (rc == NGCF_OK && part.n_heavy > 0) rc = upload(&part.heavy_seg_ptr, heavy_ptr, stream);
     if (rc == NGCF_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(NGCF_ERR_HIP, "swept plan: upload failed");
@@ -562,6 +566,7 @@ struct SweptPartArgs {
     const int32_t *e_pack;
     const float *e_val;
     const int32_t *dst;
+    const int32_t *prow;
     float *partial;
     int n_rowpass, n_win, lead;
 };
@@ -570,11 +575,14 @@ struct SweptLaunch {
     int n_parts;
 };
 
-template <int RW, int NW, bool DBG>
+// DROP: device-mode node dropout (common.h, EdgeDrop): a lane tests the entry it holds when it loads it - row from the wave's
+// table of matrix rows (one ds_bpermute), column from the packed entry - and zeroes the value of a dropped entry; the gather of
+// a dropped entry still happens (the round structure is fixed by the plan), its product is 0.
+template <int RW, int NW, bool DBG, bool DROP>
 __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int n_slices, const float *__restrict__ E,
                                                              int64_t ldE, float *__restrict__ out, int64_t ldo, int dp, unsigned *bar,
                                                              int max_spin, int sync_k, unsigned prio_cols, int prio_graded, int nt_flags,
-                                                             unsigned long long *__restrict__ dbg)
+                                                             unsigned long long *__restrict__ dbg, EdgeDrop dr)
 {
     __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];
@@ -613,6 +621,9 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
         const int64_t task = ((int64_t)rp * gridDim.x + blockIdx.x) * NW + wave;
         const int64_t *tp = tptr + task * n_win;
         const int64_t beg = tp[0], end = tp[n_win];
+        int my_row = 0, my_row_hi = 0;           // lane lr (and lr - 64): the matrix row behind accumulator row lr of this task
+        if (DROP && lane < RW) my_row = L.part[pi].prow[task * RW + lane];
+        if (DROP && RW > 64 && lane + 64 < RW) my_row_hi = L.part[pi].prow[task * RW + 64 + lane];
         for (int slice = 0; slice < n_slices; ++slice, ++sweep_no, step0 += (n_win + sync_k - 1) / sync_k) {   // sweep step = sync_k windows
             const char *Eb = reinterpret_cast<const char *>(E + slice * kSW);   // uniform base + 32-bit lane offsets
             for (int i = lane; i < (RW + 1) * kSW; i += 64) wacc[i] = 0.f;
@@ -680,6 +691,15 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
                 }
                 pk = idx < end ? pk_l : idle_pk;
                 v = idx < end ? v_l : 0.f;
+                if (DROP) {
+                    const int lr = (pk >> kRowBits) & 0x7f;                      // RW (the spare row) for idle slots: any row will do
+                    int grow = __shfl(my_row, lr < RW ? lr & 63 : 0);
+                    if (RW > 64) {
+                        const int hi = __shfl(my_row_hi, lr & 63);
+                        grow = lr >= 64 && lr < RW ? hi : grow;
+                    }
+                    v = edge_keep(dr, grow, pk & kColMask) ? v : 0.f;
+                }
             };
             if (end > beg) {
                 int pkA, pkB;
@@ -782,7 +802,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
 
 // kernels + fix-ups of every part; `partial` = workspace base (rows of dp floats)
 int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *out, int64_t ldo, float *partial, int dp,
-                 hipStream_t stream)
+                 hipStream_t stream, const EdgeDrop &dr)
 {
     const ngcf_csr::Swept &w = c->swept;
     const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);                       // polls before a wave stops waiting for good
@@ -815,7 +835,7 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
             const auto &p = w.parts[p1];
             // sweep steps a wave may run ahead: by the size of the part's table
             const int lead = std::min(lead_env != -2 ? lead_env : (p.n_win >= 8 ? 2 : 1), kRing - 4);
-            L.part[L.n_parts++] = SweptPartArgs{p.tptr, p.e_pack, p.e_val, p.dst, partial ? partial + p.partial_base * (int64_t)dp : nullptr,
+            L.part[L.n_parts++] = SweptPartArgs{p.tptr, p.e_pack, p.e_val, p.dst, p.prow, partial ? partial + p.partial_base * (int64_t)dp : nullptr,
                                                 p.n_rowpass, p.n_win, lead};
         }
         const int waves = w.parts[p0].waves;
@@ -826,15 +846,18 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
             HIP_TRY(hipMalloc(&dbg, dbg_words * 8));
             HIP_TRY(hipMemsetAsync(dbg, 0, dbg_words * 8, stream));
         }
-#define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_)                                                                                          \
-    spmm_swept_kernel<RW_, NW_, DBG_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, w.barrier, max_spin,  \
-                                                                               sync_k, prio_cols, prio_graded, nt_flags, dbg)
+#define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_, DROP_)                                                                                    \
+    spmm_swept_kernel<RW_, NW_, DBG_, DROP_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, w.barrier,  \
+                                                                                      max_spin, sync_k, prio_cols, prio_graded,    \
+                                                                                      nt_flags, dbg, dr)
         if (waves == 16) {
-            if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true);
-            else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false);
+            if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, true);
+            else if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true, false);
+            else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, false);
         } else {
-            if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, true);
-            else NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false);
+            if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false, true);
+            else if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, true, false);
+            else NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false, false);
         }
 #undef NGCF_SWEPT_LAUNCH
         LAUNCH_CHECK();

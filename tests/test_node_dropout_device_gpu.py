@@ -54,6 +54,40 @@ def test_dropout_spmm_matches_host_mask_and_statistics():
         assert float((got - want).abs().max()) <= 2e-6 * max(scale, 1.0)
 
 
+def test_dropout_on_the_swept_kernel_and_on_the_transpose():
+    """The same mask whatever walks the matrix: the L2-swept kernel (forced onto a small matrix, rows cut into pieces
+    included), the row-wise kernels, and the CSR of L^T with `transposed` set - L^T loses exactly the entries L lost."""
+    import seoul_tourism_recommendation_ngcf_amd as pkg
+    eng = pkg.engine
+    dev = torch.device("cuda:0")
+    coo = pkg.graphs.synthetic_bipartite(20000, 300, 400000, seed=9, device=dev)      # 300 item rows of ~1 300 entries: cut rows
+    N = coo["n_user"] + coo["n_item"]
+    rows, cols, vals = coo["rows"], coo["cols"], coo["vals"]
+    X = torch.randn((N, 128), generator=torch.Generator(device=dev).manual_seed(2), device=dev)
+    seeds, p = [77, 1234567], 0.25
+    keep = torch.from_numpy(keep_mask(rows.cpu().numpy(), cols.cpu().numpy(), seeds, p)).to(dev)
+    thin = eng.LaplacianCSR.from_coo(rows[keep], cols[keep], vals[keep], N, N)
+    want = eng.spmm(thin, X)
+    scale = max(float(want.abs().max()), 1.0)
+    csr = eng.LaplacianCSR.from_coo(rows, cols, vals, N, N)
+    plain = eng.spmm(csr, X, edge_drop=(seeds, p, False))
+    assert float((plain - want).abs().max()) <= 2e-6 * scale
+    csr.set_mode(2)                                                                    # swept wherever the shape allows
+    assert csr.swept_rows == N
+    swept = eng.spmm(csr, X, edge_drop=(seeds, p, False))
+    assert float((swept - want).abs().max()) <= 2e-6 * scale
+    assert torch.equal(swept, eng.spmm(csr, X, edge_drop=(seeds, p, False)))           # deterministic
+    # the transpose: rows of L^T are columns of L
+    order = torch.sort(cols, stable=True).indices
+    csr_t = eng.LaplacianCSR.from_coo(cols[order], rows[order], vals[order], N, N)
+    thin_t = eng.LaplacianCSR.from_coo(cols[keep], rows[keep], vals[keep], N, N)       # (from_coo sorts)
+    want_t = eng.spmm(thin_t, X)
+    for mode in (0, 2):
+        csr_t.set_mode(mode)
+        got_t = eng.spmm(csr_t, X, edge_drop=(seeds, p, True))
+        assert float((got_t - want_t).abs().max()) <= 2e-6 * max(float(want_t.abs().max()), 1.0)
+
+
 def test_module_device_node_dropout_forward_and_gradients():
     import seoul_tourism_recommendation_ngcf_amd as pkg
     dev = torch.device("cuda:0")
