@@ -221,8 +221,8 @@ int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp
 /* Backward of the row gathers (NGCF.py:151-155): G[row_off + idx[b], :] += g[b, :]; duplicates add up. */
 int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, int64_t B, int64_t row_off,
                               int64_t n_idx_rows, const float *g, int64_t ldg, void *stream);
-/* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block),
- * dC (gradient of the carry from the next layer, may be NULL) and the saved carry C. */
+/* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block; NULL = zero:
+ * the rows no gather touched), dC (gradient of the carry from the next layer, may be NULL; not both) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
                            int64_t n_rows, int d, float leaky_slope, float drop_p, uint64_t drop_seed,
                            const float *drop_mask, int64_t ld_mask, const int64_t *row_ids, float *dM, int64_t ldm, void *stream);

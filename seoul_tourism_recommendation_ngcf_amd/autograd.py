@@ -94,7 +94,7 @@ def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None, row_ids=None):
     n_rows, d = Cc.shape
     dM = torch.empty((n_rows, d), dtype=torch.float32, device=Cc.device)
     with torch.cuda.device(Cc.device):
-        _lib.check(lib.ngcf_layer_bwd_pre_f32(_ptr(dN), _row_major_ld(dN, "dN"), _ptr(dC),
+        _lib.check(lib.ngcf_layer_bwd_pre_f32(_ptr(dN), 0 if dN is None else _row_major_ld(dN, "dN"), _ptr(dC),
                                               0 if dC is None else _row_major_ld(dC, "dC"), _ptr(Cc),
                                               _row_major_ld(Cc, "C"), n_rows, d, leaky, float(drop_p), int(seed),
                                               _ptr(mask), 0 if mask is None else _row_major_ld(mask, "drop_mask"),
@@ -217,27 +217,36 @@ class Propagate(torch.autograd.Function):
         les, carries = saved[1:1 + n], saved[1 + n:1 + 2 * n]
         params = saved[1 + 2 * n:]
         w1, w2 = params[:n], params[2 * n:3 * n]
-        g_all = g_all.contiguous()
         ws = ctx.owner._ws
         gw1, gb1, gw2, gb2 = [None] * n, [None] * n, [None] * n, [None] * n
         dC = None
         offs = [sum(widths[:k + 1]) for k in range(n)]
-        # The gradient that reaches all_E from the row gathers is non-zero on at most 3 B rows (GatherTriple tags it with
-        # them).  The LAST layer's backward then involves those rows only: normalise/LeakyReLU backward, both weight
-        # gradients and the input gradients on a compacted [R, d] problem, and L^T . dLE as a scatter over the stored entries of
-        # those R rows of L (ngcf_spmm_scatter_rows_f32: ~1 M entries instead of 100 M on C3) - instead of a full SpMM and four
-        # passes over 1.1 M rows.  Earlier layers are dense (their dC is).
-        sparse_rows = getattr(g_all, "_ngcf_rows", None) if SPARSE_LAST_LAYER else None
+        # The gradient that reaches all_E from the row gathers is non-zero on at most 3 B rows, and GatherTriple hands it over as a
+        # row-sparse tensor (rows + a compact [R, D] block of values; autograd densifies it only if another consumer of all_E
+        # adds a dense gradient).  The LAST layer's backward then involves those rows only: normalise/LeakyReLU backward, both
+        # weight gradients and the input gradients on a compacted [R, d] problem, and L^T . dLE as a scatter over the stored
+        # entries of those R rows of L (ngcf_spmm_scatter_rows_f32: ~1 M entries instead of 100 M on C3) - instead of a full
+        # SpMM and four passes over 1.1 M rows.  Earlier layers are dense (their dC is), but the part of their incoming
+        # gradient that comes through the normalised all_E block is still confined to the R rows: the dense pass runs with
+        # dN = 0 and the R rows are redone with their dN.
+        rows = gv = None
+        if g_all.is_sparse:
+            if SPARSE_LAST_LAYER:
+                g = g_all.coalesce()
+                rows, gv = g.indices()[0].contiguous(), g.values().contiguous()
+            else:
+                g_all = g_all.to_dense()
+        if rows is None:
+            g_all = g_all.contiguous()
         for k in reversed(range(n)):
             d_in, d_out = widths[k], widths[k + 1]
             E_k = all_E[:, :widths[0]] if k == 0 else carries[k - 1]
             LE_k, C_k = les[k], carries[k]
             mask_k = None if ctx.masks is None else ctx.masks[k]
-            if dC is None and sparse_rows is not None:
+            if dC is None and rows is not None:
                 global sparse_last_layer_calls
                 sparse_last_layer_calls += 1
-                rows = sparse_rows
-                dM = _bwd_pre(g_all[rows, offs[k]:offs[k] + d_out], None, C_k[rows], _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
+                dM = _bwd_pre(gv[:, offs[k]:offs[k] + d_out], None, C_k[rows], _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
                               None if mask_k is None else mask_k[rows], rows)
                 LE_c, E_c = LE_k[rows], E_k[rows]
                 gW, gb = _bwd_weight(dM, LE_c, E_c, ws)
@@ -254,7 +263,12 @@ class Propagate(torch.autograd.Function):
                 _eng.spmm_scatter_rows(ctx.csrs[k], rows, dLE_c, dE, ed)         # dE += (thinned L)^T . dLE
                 dC = dE
                 continue
-            dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k], mask_k)
+            if rows is not None:
+                dM = _bwd_pre(None, dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k], mask_k)
+                dM[rows] = _bwd_pre(gv[:, offs[k]:offs[k] + d_out], dC[rows], C_k[rows], _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
+                                    None if mask_k is None else mask_k[rows], rows)
+            else:
+                dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k], mask_k)
             gW, gb = _bwd_weight(dM, LE_k, E_k, ws)                              # MFMA kernel, operand formed on the fly; bias too
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
             gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
@@ -269,7 +283,10 @@ class Propagate(torch.autograd.Function):
             _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed))     # dE += (thinned L)^T . dLE
             dC = dE
         dE0 = dC
-        _add_rows(dE0, g_all[:, :widths[0]])                                     # the all_E block of E0 itself
+        if rows is not None:
+            dE0.index_add_(0, rows, gv[:, :widths[0]])                           # the all_E block of E0 itself, R rows
+        else:
+            _add_rows(dE0, g_all[:, :widths[0]])
         return (None, None, None, None, None, None, None, None, dE0[:U], dE0[U:], *gw1, *gb1, *gw2, *gb2)
 
 
@@ -290,18 +307,25 @@ class GatherTriple(torch.autograd.Function):
         lib = _lib.load()
         idx = ctx.saved_tensors
         N, D = ctx.shape
-        G = torch.zeros((N, D), dtype=torch.float32, device=grads[0].device)
         offs = (0, ctx.U, ctx.U)
-        lims = (ctx.U, N - ctx.U, N - ctx.U)
-        with torch.cuda.device(G.device):
-            for g, ix, off, lim in zip(grads, idx, offs, lims):
-                if g is None:
-                    continue
-                g = g.contiguous()
-                _lib.check(lib.ngcf_scatter_add_rows_f32(_ptr(G), D, D, _ptr(ix), ix.numel(), off, lim, _ptr(g), D, _stream()))
-        # the rows G is non-zero on (sorted, unique; one host sync for the count): if this tensor reaches Propagate.backward
-        # as it is - no other consumer of all_E added to it - the last layer's backward runs on those rows only
-        G._ngcf_rows = torch.unique(torch.cat([ix + off for ix, off in zip(idx, offs)]))
+        live = [(g.contiguous(), ix + off) for g, ix, off in zip(grads, idx, offs) if g is not None]
+        dev = idx[0].device
+        if not live:
+            return (torch.zeros((N, D), dtype=torch.float32, device=dev), None, None, None, None, None)
+        # The gradient of all_E is non-zero on the gathered rows only (<= 3 B of N): it is handed over as a row-sparse tensor -
+        # the sorted unique rows (one host sync for their count) and a compact [R, D] block the duplicates are added into -
+        # instead of a zero-filled [N, D] matrix (2.3 GB at C3).  Propagate.backward works on those rows; any other consumer of
+        # all_E gets the dense sum from autograd.
+        rows, inv = torch.unique(torch.cat([r for _, r in live]), return_inverse=True)
+        R = int(rows.numel())
+        vals = torch.zeros((R, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            at = 0
+            for g, r in live:
+                ix = inv[at:at + r.numel()].contiguous()
+                at += r.numel()
+                _lib.check(lib.ngcf_scatter_add_rows_f32(_ptr(vals), D, D, _ptr(ix), ix.numel(), 0, R, _ptr(g), D, _stream()))
+        G = torch.sparse_coo_tensor(rows[None], vals, (N, D), is_coalesced=True)
         return (G, None, None, None, None, None)
 
 

@@ -103,22 +103,25 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
     if (r >= n_rows) return;
     const int64_t r_hash = row_ids ? row_ids[r] : r;         // compacted rows: the hash stream is indexed by the row of the matrix
     const int lane = threadIdx.x & 63;
-    const float *c = C + r * ldC, *g = dN + r * ldn;
-    float ss = 0.f, dot = 0.f;
-    for (int j = lane; j < d; j += 64) {
-        ss = fmaf(c[j], c[j], ss);
-        dot = fmaf(c[j], g[j], dot);
+    const float *c = C + r * ldC, *g = dN ? dN + r * ldn : nullptr;   // dN == nullptr: no gradient through the normalised block
+    float den = 1.f, ydot = 0.f;
+    if (g) {
+        float ss = 0.f, dot = 0.f;
+        for (int j = lane; j < d; j += 64) {
+            ss = fmaf(c[j], c[j], ss);
+            dot = fmaf(c[j], g[j], dot);
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float nrm = sqrtf(ss);
+        const bool clamped = nrm < 1e-12f;                   // F.normalize's clamp_min: N = C / eps there
+        den = clamped ? 1e-12f : nrm;
+        ydot = clamped ? 0.f : dot / (den * den);            // (y.dy)/|x| with y = x/|x|
     }
-    ss = wave_sum(ss);
-    dot = wave_sum(dot);
-    const float nrm = sqrtf(ss);
-    const bool clamped = nrm < 1e-12f;                       // F.normalize's clamp_min: N = C / eps there
-    const float den = clamped ? 1e-12f : nrm;
-    const float ydot = clamped ? 0.f : dot / (den * den);    // (y.dy)/|x| with y = x/|x|
     const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     for (int j = lane; j < d; j += 64) {
-        float t = g[j] / den - c[j] * (ydot / den);
+        float t = g ? g[j] / den - c[j] * (ydot / den) : 0.f;
         if (dC) t += dC[r * ldc + j];
         if (drop_mask) {
             t *= drop_mask[r * ldk + j];                      // the host-drawn noise tensor of the forward (0 or 1/(1-p))
@@ -136,7 +139,7 @@ extern "C" int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float 
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows == 0) return NGCF_OK;
-    if (!dN || !C || !dM || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_pre: bad argument");
+    if ((!dN && !dC) || !C || !dM || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_pre: bad argument");
     layer_bwd_pre_kernel<<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
                                                                                  seed, drop_mask, ld_mask, row_ids, dM, ldm);
     LAUNCH_CHECK();

@@ -21,7 +21,7 @@ def _pkg():
     return pkg
 
 
-def _oracle_grads(g, sd, b, node_flag, rng_state=None, wd=0.025):
+def _oracle_grads(g, sd, b, node_flag, rng_state=None, wd=0.025, extra=0.0):
     n_layer = len(g["layers"])
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(("w1_list", "w2_list", "item_emb"))}
     uw = torch.from_numpy(g["out_user_weight_after"]).clone().requires_grad_(True)     # state after the injection
@@ -36,6 +36,8 @@ def _oracle_grads(g, sd, b, node_flag, rng_state=None, wd=0.025):
                                 training=False, node_dropout=float(g["meta"][5]), node_flag=node_flag)
     u, p, n = orc.gather_torch(all_E, int(g["meta"][0]), b["u_id"], b["pos_item"], b["neg_item"])
     loss = orc.bpr_torch(u, p, n, wd, len(b["u_id"]))
+    if extra:                                      # a second, dense consumer of all_E (the item block)
+        loss = loss + extra * all_E[int(g["meta"][0]):].pow(2).sum()
     loss.backward()
     grads = {k: v.grad for k, v in leaves.items()}
     grads["user_embedding.weight"] = uw.grad
@@ -70,6 +72,31 @@ def test_parameter_gradients_match_oracle_autograd(name, node_flag, dev):
         np.testing.assert_allclose(got.cpu().numpy(), wg.numpy(), atol=2e-3 * scale + 1e-9, rtol=2e-3, err_msg=k)
     for k in ("age_emb.weight", "sex_emb.weight", "month_emb.weight", "day_emb.weight", "dow_emb.weight"):
         assert named[k].grad is None               # the injection goes through .data (NGCF.py:114): no gradient
+
+
+def test_gradients_with_a_second_consumer_of_all_E(dev):
+    """GatherTriple hands the gradient of all_E over as a row-sparse tensor; when something else also uses all_E (here a penalty on
+    `model.all_items_emb`) autograd adds a dense gradient to it and Propagate.backward takes its dense path: same gradients as
+    torch autograd through the oracle."""
+    pkg = _pkg()
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    g = load_golden("fwd_sigB_y19")
+    sd, b = sd_of(g), batch_of(g)
+    model = pkg.NGCF(**ctor_args(g, lap_list_of(g, dev), dev)).to(dev)
+    model.load_state_dict(sd)
+    model.eval()
+    batch = {k: v.to(dev) for k, v in b.items()}
+    u, p, n = model(node_flag=False, **batch)
+    before = ag.sparse_last_layer_calls
+    loss = pkg.BPR(0.025, len(b["u_id"]))(u, p, n) + 0.01 * model.all_items_emb.pow(2).sum()
+    loss.backward()
+    assert ag.sparse_last_layer_calls == before    # a dense gradient arrived: no row-sparse shortcut
+    want_loss, want = _oracle_grads(g, sd, b, False, extra=0.01)
+    assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss)
+    named = dict(model.named_parameters())
+    for k, wg in want.items():
+        scale = float(wg.abs().max())
+        np.testing.assert_allclose(named[k].grad.cpu().numpy(), wg.numpy(), atol=2e-3 * scale + 1e-9, rtol=2e-3, err_msg=k)
 
 
 def test_training_step_with_adam_runs_and_lowers_the_loss(dev):
