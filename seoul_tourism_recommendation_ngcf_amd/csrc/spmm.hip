@@ -510,7 +510,8 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     // 16-byte aligned rows the product runs as a wide main panel on the fast kernels plus a narrow tail panel.
     const bool rows_aligned = (ldE % 4 == 0) && (ldo % 4 == 0) && aligned16(E) && aligned16(out);
     // (measured at 130 on C3: 19.5 -> 18.7 ms per forward; with edge dropout the second pass over the entries costs
-    // more than the scalar loads, so those products stay in one piece)
+    // more than the scalar loads on the row-wise kernels, so there those products stay in one piece - they are split
+    // only when the main panel then runs on the swept kernel)
     if (rows_aligned && d > 4 && !getenv("NGCF_NO_PANEL_SPLIT")) {
         int main = 0;
         if (d % 64 != 0 && d > 64 && swept_usable(c, ldE, d & ~63)) main = d & ~63;                // swept kernel + tail
