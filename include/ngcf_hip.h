@@ -139,6 +139,9 @@ int ngcf_spmm_csr_dropout_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE
  * noise tensor nn.Dropout multiplies by (0 or 1/(1-p)), drawn by the caller - the mirror draws it from torch's CPU
  * generator exactly where the reference does, so the zero pattern is bit-identical ("reference" mode); drop_mask == NULL
  * and drop_p > 0: keep mask = counter-based hash of (drop_seed, row, column) evaluated in the epilogue ("device" mode).
+ * One call, two phases on the stream: the SpMM writes LE [n_rows, d_in] into the workspace and the dense phase (everything from
+ * the nn.Linear contractions to both outputs in one kernel) reads it back; what is fused is the dense half and its epilogue, not
+ * the SpMM into it (DESIGN.md 4.2 says why).
  */
 int ngcf_layer_fused_f32(const ngcf_csr_t *csr, const float *E_gather, int64_t ldEg,
                          const float *E_self, int64_t ldEs, int d_in,
