@@ -315,7 +315,7 @@ def test_default_segment_length_follows_the_matrix_size(dev, oracle_clib):
     assert small.n_segments == sum(-(-int(k) // 64) for k in np.bincount(rows[:5000], minlength=N) if k > 64)
 
 
-@pytest.mark.parametrize("d,order", [(64, "cols"), (128, "cols"), (256, "cols"), (128, "rows")])
+@pytest.mark.parametrize("d,order", [(64, "cols"), (128, "cols"), (256, "cols"), (128, "rows"), (576, "cols")])
 def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, monkeypatch):
     """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the L2-swept
     kernel (forced; both layouts of a wave's entry list inside a window) and the plain row-wise kernel must give the
