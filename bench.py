@@ -7,6 +7,8 @@
 Workload (BASELINE.json configs[2..3]): synthetic bipartite graph, 1 M users x 100 K items,
 50 M drawn interactions (popularity-skewed items, de-duplicated; the actual count is reported), both triangles
 stored -> nnz(L) = 2 x interactions; d0 = d = 128, 3 layers, fp32, random-init weights, batch of 1024 triplets.
+Secondary fields of the same line at N = 1 (labelled, never the headline): the reference-legal width 130 through the whole
+NGCF.forward, and the Seoul-shaped BASELINE configs 0-1 (c1, c2) replayed as hipGraphs.
 One "step" = one pass of the hot path: E0 -> 3 x (L.E SpMM + fused dense/LeakyReLU/normalise) -> all_E,
 3 row gathers, fused BPR loss  (NGCF.py:120-156 + bprloss.py:15-22).  The feature injection (NGCF.py:103-115)
 is not part of the step at this width: the reference itself raises for embed_size = 128 (not a multiple of 5).
@@ -358,6 +360,40 @@ def main():
             del m5
         except Exception as exc:  # noqa: BLE001
             secondary["reference_legal_width"] = {"error": repr(exc)[:300]}
+
+    if world == 1 and not seoul and not args.no_secondary:
+        # BASELINE configs 0-1 (Seoul-shaped stand-in graph, 2 layers, d = 64 / 512): the whole NGCF.forward incl. the feature
+        # injection + BPR, replayed as a hipGraph - launch-bound sizes, reported beside the headline
+        for wl in ("c1", "c2"):
+            try:
+                nu, ni, _, e0, lay_s, sd_s = WORKLOADS[wl]
+                coo_s = pkg.graphs.seoul_standin(dev, seed=sd_s, n_user=nu, n_item=ni)[0]
+                nd_s = {"user": nu, "item": ni, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+                torch.manual_seed(sd_s)
+                ms = pkg.NGCF(e0, list(lay_s), None, None, 1.0, [pkg.graphs.to_sparse_coo(coo_s)], nd_s, args.batch, dev).to(dev).eval()
+                ms.check_indices = False
+                gs = torch.Generator(device="cpu").manual_seed(sd_s + 1)
+                ids = {k: torch.randint(0, c, (args.batch,), generator=gs).to(dev)
+                       for k, c in (("u_id", nu), ("pos_item", ni), ("neg_item", ni), ("age", 76), ("sex", 2), ("month", 13),
+                                    ("day", 32), ("dow", 7))}
+                fwd_s = pkg.GraphedForward(ms, args.batch, 0)
+                fwd_s(year=torch.full((args.batch,), 18, device=dev), node_flag=False, **ids)
+                crit_s = pkg.BPR(0.025, args.batch)
+                for _ in range(20):
+                    ls = crit_s(*fwd_s.replay())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    ls = crit_s(*fwd_s.replay())
+                torch.cuda.synchronize()
+                ms_step = (time.perf_counter() - t0) / 200 * 1e3
+                secondary[f"{wl}_seoul_shaped_hipgraph"] = {
+                    "ms_per_step": ms_step, "value": len(lay_s) * coo_s["nnz"] / (ms_step * 1e-3), "unit": "edges/s", "loss": float(ls),
+                    "note": f"{nu} users x {ni} items, nnz(L)={coo_s['nnz']}, embed_size={e0}, layers={list(lay_s)}, batch={args.batch}: "
+                            "NGCF.forward (injection, propagation, gathers) replayed as a hipGraph + BPR, 200 steps after 20"}
+                del fwd_s, ms
+            except Exception as exc:  # noqa: BLE001
+                secondary[f"{wl}_seoul_shaped_hipgraph"] = {"error": repr(exc)[:300]}
 
     swept = [csr.swept_rows] if world == 1 else sh.swept_rows()
     kernel_name = ("spmm_swept_kernel (one L.E product: a launch per row group + fix-up)" if all(swept) else
