@@ -93,7 +93,7 @@ def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None, row_ids=None):
     lib = _lib.load()
     n_rows, d = Cc.shape
     dM = torch.empty((n_rows, d), dtype=torch.float32, device=Cc.device)
-    with torch.cuda.device(Cc.device):
+    with _eng._on(Cc.device):
         _lib.check(lib.ngcf_layer_bwd_pre_f32(_ptr(dN), 0 if dN is None else _row_major_ld(dN, "dN"), _ptr(dC),
                                               0 if dC is None else _row_major_ld(dC, "dC"), _ptr(Cc),
                                               _row_major_ld(Cc, "C"), n_rows, d, leaky, float(drop_p), int(seed),
@@ -106,7 +106,7 @@ def _sp_concat(LE, E):
     lib = _lib.load()
     n_rows, d = LE.shape
     SP = torch.empty((n_rows, 2 * d), dtype=torch.float32, device=LE.device)
-    with torch.cuda.device(LE.device):
+    with _eng._on(LE.device):
         _lib.check(lib.ngcf_sp_concat_f32(_ptr(LE), _row_major_ld(LE, "LE"), _ptr(E), _row_major_ld(E, "E"), n_rows, d,
                                           _ptr(SP), _stream()))
     return SP
@@ -123,7 +123,7 @@ def _bwd_weight(dM, LE, E, ws):
     gb = torch.empty((d_out,), dtype=torch.float32, device=dM.device)
     nb = int(lib.ngcf_bwd_weight_workspace_bytes())
     w = ws.get(nb, dM.device)
-    with torch.cuda.device(dM.device):
+    with _eng._on(dM.device):
         for o0 in range(0, d_out, 128):
             o1 = min(d_out, o0 + 128)
             for c0 in range(0, d_in, 128):
@@ -146,7 +146,7 @@ def _bwd_combine(dSP, LE, E):
     d4 = (d + 31) // 32 * 32   # 128-byte aligned rows: L^T . dLE then runs on the float4 / swept kernels at any width
     dLE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
     dE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
-    with torch.cuda.device(LE.device):
+    with _eng._on(LE.device):
         _lib.check(lib.ngcf_layer_bwd_combine_f32(_ptr(dSP), _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E),
                                                   _row_major_ld(E, "E"), n_rows, d, _ptr(dLE), d4, _ptr(dE), d4, _stream()))
     return dLE, dE
@@ -162,7 +162,7 @@ def _bwd_input(dM, w1, w2, LE, E, ws):
     dE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d_in]
     w1, w2 = w1.contiguous(), w2.contiguous()
     w = ws.get(int(lib.ngcf_layer_bwd_input_workspace_bytes(d_out)), dM.device)
-    with torch.cuda.device(dM.device):
+    with _eng._on(dM.device):
         _lib.check(lib.ngcf_layer_bwd_input_f32(_ptr(dM), _row_major_ld(dM, "dM"), n_rows, d_out, _ptr(w1), _ptr(w2), d_in,
                                                 _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E), _row_major_ld(E, "E"),
                                                 _ptr(dLE), d4, _ptr(dE), d4, _ptr(w), w.numel(), _stream()))
@@ -171,7 +171,7 @@ def _bwd_input(dM, w1, w2, LE, E, ws):
 
 def _add_rows(out, add):
     lib = _lib.load()
-    with torch.cuda.device(out.device):
+    with _eng._on(out.device):
         _lib.check(lib.ngcf_add_rows_f32(_ptr(out), _row_major_ld(out, "out"), _ptr(add), _row_major_ld(add, "add"),
                                          out.shape[0], out.shape[1], _stream()))
 
@@ -319,7 +319,7 @@ class GatherTriple(torch.autograd.Function):
         rows, inv = torch.unique(torch.cat([r for _, r in live]), return_inverse=True)
         R = int(rows.numel())
         vals = torch.zeros((R, D), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _eng._on(dev):
             at = 0
             for g, r in live:
                 ix = inv[at:at + r.numel()].contiguous()
@@ -344,7 +344,7 @@ class BPRLoss(torch.autograd.Function):
         u, p, n = (t.contiguous() for t in ctx.saved_tensors)
         du, dp, dn = torch.empty_like(u), torch.empty_like(p), torch.empty_like(n)
         g = g.to(torch.float32).contiguous()
-        with torch.cuda.device(u.device):
+        with _eng._on(u.device):
             _lib.check(lib.ngcf_bpr_backward_f32(_ptr(u), u.shape[0], _ptr(p), p.shape[0], _ptr(n), n.shape[0], u.shape[1],
                                                  ctx.wd, ctx.bs, _ptr(g), _ptr(du), _ptr(dp), _ptr(dn), _stream()))
         return du, dp, dn, None, None, None

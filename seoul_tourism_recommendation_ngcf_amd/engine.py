@@ -34,7 +34,34 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(device):
+    """`torch.cuda.device(device)`, or nothing at all when that device is already current (the context manager costs ~8 us per
+    use, a dozen times per forward on a launch-bound graph)."""
+    dev = torch.device(device)
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NULL
+    return torch.cuda.device(dev)
+
+
 def _stream():
+    """torch's current stream on the current device as a hipStream_t.  (The raw getter where this torch has it: the Stream
+    object of `torch.cuda.current_stream()` costs ~8 us to build, seven times per forward on a launch-bound graph.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -76,7 +103,7 @@ class LaplacianCSR:
         if not (rows.numel() == cols.numel() == vals.numel()):
             raise RuntimeError("Laplacian COO arrays differ in length")
         out = C.c_void_p()
-        with torch.cuda.device(vals.device):
+        with _on(vals.device):
             _lib.check(lib.ngcf_csr_from_coo(_ptr(rows), _ptr(cols), _ptr(vals), rows.numel(), n_rows, n_cols,
                                              C.byref(out), _stream()))
         return cls(out.value)
@@ -105,7 +132,7 @@ class LaplacianCSR:
         assert rowptr.dtype == torch.int64 and colidx.dtype == torch.int32 and vals.dtype == torch.float32
         rowptr, colidx, vals = rowptr.contiguous(), colidx.contiguous(), vals.contiguous()
         out = C.c_void_p()
-        with torch.cuda.device(vals.device):
+        with _on(vals.device):
             _lib.check(lib.ngcf_csr_from_arrays(_ptr(rowptr), _ptr(colidx), _ptr(vals), rowptr.numel() - 1, n_cols,
                                                 colidx.numel(), C.byref(out), _stream()))
         return cls(out.value, keep_alive=(rowptr, colidx, vals))
@@ -186,7 +213,7 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
     ws = ws or Workspace()
     nb = csr.spmm_workspace_bytes(d)
     w = ws.get(nb, E.device)
-    with torch.cuda.device(E.device):
+    with _on(E.device):
         if edge_drop is None:
             _lib.check(lib.ngcf_spmm_csr_f32(csr._h, _ptr(E), _row_major_ld(E, "E"), d, _ptr(out),
                                              _row_major_ld(out, "out"), _ptr(w), w.numel(), _stream()))
@@ -211,7 +238,7 @@ def spmm_scatter_rows(csr: LaplacianCSR, rows: torch.Tensor, X: torch.Tensor, ou
         raise RuntimeError("spmm_scatter_rows: shape mismatch")
     seeds, p = edge_drop if edge_drop is not None else ((), 0.0)
     arr = (C.c_uint64 * max(len(seeds), 1))(*[int(x) & (2 ** 64 - 1) for x in seeds])
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _lib.check(lib.ngcf_spmm_scatter_rows_f32(csr._h, _ptr(rows), rows.numel(), csr.max_row_len, _ptr(X), _row_major_ld(X, "X"),
                                                   int(X.shape[1]), _ptr(out), _row_major_ld(out, "out"), float(p), arr, len(seeds),
                                                   _stream()))
@@ -233,7 +260,7 @@ def layer_fused(csr: LaplacianCSR, E_gather: torch.Tensor, E_self: torch.Tensor,
     W1, W2, b1, b2 = W1.contiguous(), W2.contiguous(), b1.contiguous(), b2.contiguous()
     nb = csr.layer_workspace_bytes(d_in, d_out)
     w = ws.get(nb, norm.device)
-    with torch.cuda.device(norm.device):
+    with _on(norm.device):
         _lib.check(lib.ngcf_layer_fused_f32(
             csr._h, _ptr(E_gather), _row_major_ld(E_gather, "E_gather"), _ptr(E_self), _row_major_ld(E_self, "E_self"),
             d_in, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), d_out, LEAKY_SLOPE, float(drop_p), int(drop_seed),
@@ -252,7 +279,7 @@ def layer_dense(LE: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2, carry, n
     if nb < 0:
         raise RuntimeError(f"unsupported layer widths d_in={d_in} d_out={d_out}")
     w = ws.get(nb, norm.device)
-    with torch.cuda.device(norm.device):
+    with _on(norm.device):
         _lib.check(lib.ngcf_layer_dense_f32(
             _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E_self), _row_major_ld(E_self, "E_self"), LE.shape[0], d_in,
             _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), d_out, LEAKY_SLOPE, float(drop_p), int(drop_seed),
@@ -269,7 +296,7 @@ def copy_rows(src: torch.Tensor, dst: torch.Tensor, dst2: Optional[torch.Tensor]
         raise RuntimeError(f"copy_rows: shape mismatch {tuple(src.shape)} vs {tuple(dst.shape)}")
     if src.shape[0] == 0:
         return
-    with torch.cuda.device(dst.device):
+    with _on(dst.device):
         if dst2 is None:
             _lib.check(lib.ngcf_copy_rows_f32(_ptr(src), _row_major_ld(src, "src"), _ptr(dst), _row_major_ld(dst, "dst"),
                                               src.shape[0], src.shape[1], _stream()))
@@ -290,7 +317,7 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor, ro
     out = torch.empty((B, d), dtype=torch.float32, device=table.device)
     if n_idx_rows is None:
         n_idx_rows = int(table.shape[0]) - row_off
-    with torch.cuda.device(table.device):
+    with _on(table.device):
         _lib.check(lib.ngcf_gather_rows_f32(_ptr(table), _row_major_ld(table, "table"), d, _ptr(idx), B, row_off,
                                             n_idx_rows, _ptr(out), d, _ptr(status), _stream()))
     return out
@@ -312,7 +339,7 @@ def gather_rows3(table: torch.Tensor, sets, status: torch.Tensor):
         out = torch.empty((int(idx.numel()), d), dtype=torch.float32, device=table.device)
         args += [_ptr(idx), int(idx.numel()), int(row_off), int(n_rows), _ptr(out)]
         outs.append(out)
-    with torch.cuda.device(table.device):
+    with _on(table.device):
         _lib.check(lib.ngcf_gather_rows3_f32(_ptr(table), _row_major_ld(table, "table"), d, *args, d, _ptr(status), _stream()))
     return outs
 
@@ -336,7 +363,7 @@ def feature_inject(user_w: torch.Tensor, tables: Sequence[torch.Tensor], idx: Se
     t_arr = (C.c_void_p * 5)(*[t.data_ptr() for t in tabs])
     i_arr = (C.c_void_p * 5)(*[i.data_ptr() for i in ids])
     c_arr = (C.c_int64 * 5)(*[int(t.shape[0]) for t in tabs])
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.ngcf_feature_inject_f32(_ptr(user_w), user_w.shape[1], user_w.shape[0], user_w.shape[1],
                                                t_arr, i_arr, c_arr, fw, _ptr(u_id), B, float(emb_ratio),
                                                _ptr(scratch), _ptr(status), _stream()))
@@ -360,7 +387,7 @@ def bpr_loss(u: torch.Tensor, p: torch.Tensor, n: torch.Tensor, weight_decay: fl
     nb = int(lib.ngcf_bpr_workspace_bytes(R))
     w = ws.get(nb, u.device)
     loss = torch.empty((), dtype=torch.float32, device=u.device)
-    with torch.cuda.device(u.device):
+    with _on(u.device):
         _lib.check(lib.ngcf_bpr_fused_f32(_ptr(u), u.shape[0], _ptr(p), p.shape[0], _ptr(n), n.shape[0], D,
                                           float(weight_decay), float(batch_size), _ptr(loss), _ptr(w), w.numel(),
                                           _stream()))
@@ -377,7 +404,7 @@ def topk_rows(scores: torch.Tensor, k: int):
     scores = scores if scores.stride(1) == 1 else scores.contiguous()
     vals = torch.empty((n_rows, k), dtype=torch.float32, device=scores.device)
     idx = torch.empty((n_rows, k), dtype=torch.int64, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _lib.check(lib.ngcf_topk_rows_f32(_ptr(scores), _row_major_ld(scores, "scores"), n_rows, n_cols, int(k), _ptr(vals),
                                           _ptr(idx), _stream()))
     return vals, idx
@@ -398,7 +425,7 @@ def recommend_topk(u_emb: torch.Tensor, item_emb: torch.Tensor, k: int, return_s
     scores = torch.empty((B, n_items), dtype=torch.float32, device=u_emb.device)
     vals = torch.empty((B, k), dtype=torch.float32, device=u_emb.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=u_emb.device)
-    with torch.cuda.device(u_emb.device):
+    with _on(u_emb.device):
         _lib.check(lib.ngcf_recommend_topk_f32(_ptr(u_emb), _row_major_ld(u_emb, "u_emb"), B, _ptr(item_emb),
                                                _row_major_ld(item_emb, "item_emb"), n_items, D, int(k), _ptr(scores), n_items,
                                                _ptr(vals), _ptr(idx), _stream()))
