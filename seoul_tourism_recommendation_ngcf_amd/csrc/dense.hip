@@ -769,13 +769,14 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     float *Wt = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
     float *bias2 = Wt + (int64_t)n_chunks * NGCF_KC * dop;
     const bool al = (ldLE % 4 == 0) && (ldEs % 4 == 0) && aligned16(LE) && aligned16(Es);
-    // 256 / 512 output columns and at most two workgroups per CU (<= 16 384 rows - the Seoul graph has 5 940): operands straight
+    // 256 / 512 output columns and at most ONE workgroup per CU (<= 8 192 rows - the Seoul graph has 5 940): operands straight
     // from global memory / L2, no staging (layer_dense_direct_kernel).  tools/dense_wide_lab.py: 94 vs 114 us at 5 940 x 515 -> 512,
-    // 50 vs 57 us at 256 -> 256; from 100 K rows on the staged kernel (two workgroups share a CU's LDS and matrix pipe) is as fast
-    // or faster (1.08 vs 1.40 ms at 100 K x 512 -> 512).  NGCF_DENSE_DIRECT=0 / 2: never / at any row count.
+    // 50 vs 57 us at 256 -> 256, 97 vs 117 us at 8 192 x 512 -> 512; as soon as a CU gets a second workgroup the staged kernel
+    // (two workgroups share a CU's LDS and matrix pipe; the direct kernel runs one wave per SIMD) wins clearly: 170 vs 277 us at
+    // 12 288 rows, 1.08 vs 1.40 ms at 100 K.  NGCF_DENSE_DIRECT=0 / 2: never / at any row count.
     const int direct_env = getenv("NGCF_DENSE_DIRECT") ? atoi(getenv("NGCF_DENSE_DIRECT")) : 1;
     const bool direct = direct_env && dop >= 256 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
-                        n_rows > 0 && (n_rows <= 16384 || direct_env == 2);
+                        n_rows > 0 && (n_rows <= 8192 || direct_env == 2);
     pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop,
                                                                                     dop <= 128 ? dop / 32 : 4, Wt, bias2);
     LAUNCH_CHECK();

@@ -22,8 +22,11 @@ def t(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
-for n, d_in, d_out in ((5940, 515, 512), (5940, 512, 512), (5940, 256, 256), (100_000, 512, 512), (100_000, 256, 256),
-                       (1_100_000, 256, 256), (1_100_000, 512, 512)):
+SHAPES = ((5940, 515, 512), (5940, 512, 512), (5940, 256, 256), (100_000, 512, 512), (100_000, 256, 256),
+          (1_100_000, 256, 256), (1_100_000, 512, 512))
+if os.environ.get("LAB_ROWS"):          # e.g. LAB_ROWS=8192,16384,32768: where the two kernels cross
+    SHAPES = tuple((int(r), di, do) for r in os.environ["LAB_ROWS"].split(",") for di, do in ((512, 512), (256, 256)))
+for n, d_in, d_out in SHAPES:
     ld = (d_in + 31) // 32 * 32
     LE = torch.randn((n, ld), device=dev)[:, :d_in]
     E = torch.randn((n, ld), device=dev)[:, :d_in]
