@@ -784,12 +784,13 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     return launch_dense<RW, CW, NT>(al, n_rows, LE, ldLE, Es, ldEs, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, \
                                     drop_seed, drop_mask, ld_mask, carry, ldc, norm, ldn, stream)
     {
-        // weights resident in LDS, no barriers (layer_dense_resident_kernel): large row counts at the 128-wide shapes
-        // (measured on C3: 0.78 vs 0.805 ms per layer; NGCF_DENSE_RESIDENT=0 keeps the staged kernel)
+        // weights resident in LDS, no barriers (layer_dense_resident_kernel): large row counts at the 128-wide shapes, from two
+        // tiles per wave on (128 -> 128, resident / staged us: 65 536 rows 59 / 59, 98 304 rows 95 / 85, 131 072 rows 96 / 104,
+        // 262 144 rows 184 / 212, C3's 1.1 M rows 633 / 780; NGCF_DENSE_RESIDENT=0 keeps the staged kernel)
         const int resident = getenv("NGCF_DENSE_RESIDENT") ? atoi(getenv("NGCF_DENSE_RESIDENT")) : 1;
         const int64_t lds_bytes = (int64_t)n_chunks * NGCF_KC * 128 * (int64_t)sizeof(float);
         if (resident && dop == 128 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
-            lds_bytes <= 150 * 1024 && n_rows >= 32 * kResWaves * kResWGs) {
+            lds_bytes <= 150 * 1024 && n_rows >= 2 * 32 * kResWaves * kResWGs) {
             static bool attr_set = false;
             if (!attr_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_kernel),
