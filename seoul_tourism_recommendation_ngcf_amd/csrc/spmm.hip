@@ -411,9 +411,10 @@ int launch_spmm(const SpmmArgs &a)
     const bool can_ldstab = VEC == 4 && a.d % 4 == 0 && c->mode != 1 && !getenv("NGCF_NO_LDSTAB");
     bool seg_done = seg_blocks == 0;
     // under capture: segments (+ fix-up at the end) on the caller's stream, every group kernel on the side stream
-    // (only where the halves are long enough to be worth a dependency edge: Seoul-shaped C2, d = 512: 0.410 -> 0.385 ms per
-    // forward; C1, d = 64: 0.121 -> 0.132 ms, so not there)
-    const bool fork = seg_blocks > 0 && !a.with_swept && !c->groups.empty() && c->nnz * (int64_t)a.d >= 200000000 &&
+    // (only where the halves are long enough to be worth a dependency edge - tools/fork_lab.py, Seoul-shaped forward as a hipGraph,
+    // fork / one branch: d = 64 0.127 / 0.112 ms, 128 0.175 / 0.164, 256 0.247 / 0.312, 384 0.319 / 0.336, 512 0.370 / 0.395)
+    const int64_t fork_min = getenv("NGCF_FORK_MIN") ? atoll(getenv("NGCF_FORK_MIN")) : 200000000;   // lab knob (tools/fork_lab.py)
+    const bool fork = seg_blocks > 0 && !a.with_swept && !c->groups.empty() && c->nnz * (int64_t)a.d >= fork_min &&
                       fork_ready(a.stream);
     hipStream_t gs = a.stream;
     if (fork) {
