@@ -41,7 +41,18 @@ typedef struct ngcf_csr ngcf_csr_t;
 const char *ngcf_last_error(void);
 /* "gfx950" - the only architecture the code objects are built for. */
 const char *ngcf_target_arch(void);
+/* ABI version of this header.  ngcf_version() returns the value the library was built with; the Python mirror refuses to bind
+ * a library whose version differs (a stale .so would otherwise receive shifted arguments). */
+#define NGCF_ABI_VERSION 3
 int ngcf_version(void);
+
+/* Tunables of the kernel dispatch (thresholds, lab switches).  The library reads its NGCF_* environment variables ONCE, in
+ * ngcf_options_from_env() on first use (no launch path touches the environment); call it again to re-read them, or set single
+ * options by name (the variable's name without the NGCF_ prefix, lower case: "dense_resident", "swept_lead", ...; the table
+ * is NgcfOptions in csrc/common.h).  Unknown names are an error.  Not thread-safe against concurrent launches. */
+int ngcf_options_from_env(void);
+int ngcf_set_option(const char *name, int64_t value);
+int ngcf_set_option_str(const char *name, const char *value);
 
 /* Timing of the dominant kernel for bench.py's roofline line: while enabled, every SpMM kernel launch is
  * bracketed by a hipEvent pair on its own stream.  ngcf_prof_collect waits for them and returns the number
@@ -109,6 +120,12 @@ int64_t ngcf_layer_workspace_bytes(const ngcf_csr_t *csr, int d_in, int d_out);
  */
 int ngcf_spmm_csr_f32(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d, float *LE,
                       int64_t ldLE, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Width to run a product at when LE has padded rows (leading dimension a multiple of 4 >= d rounded up): a width that is not
+ * a multiple of 4 on a small (launch-bound) matrix is multiplied up to the next multiple of 4 when the gathered rows are
+ * 16-byte aligned and padded - the extra columns land in the padding of LE.  ngcf_layer_fused_f32 applies this rule itself;
+ * callers that run the SpMM on its own (the training path) ask here so that both paths produce the same bits. */
+int ngcf_spmm_product_width(const ngcf_csr_t *csr, const float *E, int64_t ldE, int d);
 
 /*
  * LE = drop(L).E with node dropout on the device (NGCF.py:93-100,124-126 semantics: every stored entry is kept

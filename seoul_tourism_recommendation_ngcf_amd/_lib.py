@@ -15,6 +15,7 @@ import torch  # noqa: F401  (must be loaded before libngcf_hip.so, see module do
 from . import _build
 
 OK, ERR_ARG, ERR_HIP, ERR_INDEX, ERR_WORKSPACE = 0, 1, 2, 3, 4
+ABI_VERSION = 3          # NGCF_ABI_VERSION of include/ngcf_hip.h these prototypes were written against
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
 
@@ -23,6 +24,9 @@ PROTOTYPES = {
     "ngcf_last_error": (C.c_char_p, []),
     "ngcf_target_arch": (C.c_char_p, []),
     "ngcf_version": (C.c_int, []),
+    "ngcf_options_from_env": (C.c_int, []),
+    "ngcf_set_option": (C.c_int, [C.c_char_p, _i64]),
+    "ngcf_set_option_str": (C.c_int, [C.c_char_p, C.c_char_p]),
     "ngcf_prof_enable": (C.c_int, [C.c_int]),
     "ngcf_prof_collect": (C.c_int, [C.POINTER(_i64), C.POINTER(C.c_double)]),
     "ngcf_csr_from_coo": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(_vp), _vp]),
@@ -42,6 +46,7 @@ PROTOTYPES = {
     "ngcf_spmm_workspace_bytes": (_i64, [_vp, C.c_int]),
     "ngcf_layer_workspace_bytes": (_i64, [_vp, C.c_int, C.c_int]),
     "ngcf_dense_workspace_bytes": (_i64, [C.c_int, C.c_int]),
+    "ngcf_spmm_product_width": (C.c_int, [_vp, _vp, _i64, C.c_int]),
     "ngcf_spmm_csr_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_spmm_csr_dropout_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, C.c_int,
                                             _vp, _i64, _vp]),
@@ -87,8 +92,8 @@ def lib_path() -> str:
 def load():
     """Load libngcf_hip.so.  The library is built by `python __graft_entry__.py build` (before any GPU or profiler
     start).  If it is missing or its sources changed since, it is rebuilt here under a file lock - unless NGCF_NO_BUILD=1
-    (set it under rocprofv3 and wherever a compiler must not be spawned): then a missing library raises and a stale one
-    is loaded with a loud warning.  A failed rebuild always raises; a stale library is never used silently."""
+    (set it under rocprofv3 and wherever a compiler must not be spawned): then a missing or stale library raises
+    (NGCF_ALLOW_STALE=1: a stale one is loaded with a loud warning, after the ABI version check).  A failed rebuild always raises; a stale library is never used silently."""
     global _lib
     if _lib is not None:
         return _lib
@@ -97,7 +102,12 @@ def load():
             if not os.path.exists(_build.LIB):
                 raise RuntimeError(f"{_build.LIB} is not built and NGCF_NO_BUILD=1; run `python __graft_entry__.py build`. "
                                    "This package has no CPU or PyTorch fallback.")
-            sys.stderr.write(f"[ngcf] WARNING: {_build.LIB} is OLDER than its sources (NGCF_NO_BUILD=1: not rebuilding); "
+            # a stale library may have another ABI (shifted arguments = out-of-bounds GPU accesses, not just old results)
+            if os.environ.get("NGCF_ALLOW_STALE") != "1":
+                raise RuntimeError(f"{_build.LIB} was built from other sources than the ones in the tree and NGCF_NO_BUILD=1 "
+                                   "forbids rebuilding it here; run `python __graft_entry__.py build` first "
+                                   "(NGCF_ALLOW_STALE=1 loads it anyway, after the ABI version check).")
+            sys.stderr.write(f"[ngcf] WARNING: {_build.LIB} is OLDER than its sources (NGCF_NO_BUILD=1, NGCF_ALLOW_STALE=1): "
                              "results come from the stale library. Run `python __graft_entry__.py build`.\n")
         else:
             try:
@@ -110,12 +120,29 @@ def load():
         lib = C.CDLL(_build.LIB, mode=C.RTLD_GLOBAL)
     except OSError as exc:
         raise RuntimeError(f"cannot load {_build.LIB}: {exc}; there is no fallback path") from exc
+    lib.ngcf_version.restype = C.c_int
+    if int(lib.ngcf_version()) != ABI_VERSION:
+        raise RuntimeError(f"{_build.LIB} has ABI version {int(lib.ngcf_version())}, this package binds version {ABI_VERSION}: "
+                           "rebuild it with `python __graft_entry__.py build`")
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)        # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_option(name: str, value) -> None:
+    """One tunable of the kernel dispatch by name (include/ngcf_hip.h, ngcf_set_option): tests and tools."""
+    if isinstance(value, str):
+        check(load().ngcf_set_option_str(name.encode(), value.encode()))
+    else:
+        check(load().ngcf_set_option(name.encode(), int(value)))
+
+
+def options_from_env() -> None:
+    """Re-read the NGCF_* variables (the library reads them once, on first use)."""
+    check(load().ngcf_options_from_env())
 
 
 def last_error() -> str:

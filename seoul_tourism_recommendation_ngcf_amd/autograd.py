@@ -231,7 +231,8 @@ class Propagate(torch.autograd.Function):
         # dN = 0 and the R rows are redone with their dN.
         rows = gv = None
         if g_all.is_sparse:
-            if SPARSE_LAST_LAYER:
+            # (the row scatter keeps a row of X in 8 registers per lane: the last layer's input width must be <= 512)
+            if SPARSE_LAST_LAYER and widths[n - 1] <= 512:
                 g = g_all.coalesce()
                 rows, gv = g.indices()[0].contiguous(), g.values().contiguous()
             else:

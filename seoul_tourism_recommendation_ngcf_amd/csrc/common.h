@@ -47,6 +47,56 @@ inline int fail(int code, const char *fmt, ...)
     } while (0)
 
 
+// ---------------------------------------------------------------------------------------------
+// options: every tunable of the dispatch code in ONE struct.  csr.hip fills it once per process (the only getenv() of the
+// library is in ngcf_options_from_env there: launches never touch the environment) and ngcf_set_option changes single
+// fields at run time (tests, tools/).  Fields marked LAB select code that is compiled only with -DNGCF_LAB.
+// ---------------------------------------------------------------------------------------------
+struct NgcfOptions {
+    // spmm.hip
+    int no_fork = 0;               // NGCF_NO_FORK: never record the two halves of a row-wise product as parallel graph branches
+    int no_slicing = 0;            // NGCF_NO_SLICING: no d-sliced launches of the sliceable row groups
+    int no_ldstab = 0;             // NGCF_NO_LDSTAB: no table-in-LDS kernel
+    int no_panel_split = 0;        // NGCF_NO_PANEL_SPLIT: odd widths in one piece on the scalar kernels
+    int no_tail_table = 0;         // NGCF_NO_TAIL_TABLE: tail columns gathered out of the strided table
+    int no_pad_product = 0;        // NGCF_NO_PAD_PRODUCT: small matrices: do not multiply the padding columns along
+    int64_t fork_min = 200000000;  // NGCF_FORK_MIN: entry-columns from which the halves are forked under capture
+    int tail_overlap = 1;          // NGCF_TAIL_OVERLAP: the tail product of an odd width on a second stream beside the main panel
+    // dense.hip
+    int dense_direct = 1;          // NGCF_DENSE_DIRECT: 0 never, 1 up to 8 192 rows, 2 at any row count
+    int dense_resident = 1;        // NGCF_DENSE_RESIDENT: 0 keeps the staged kernel
+    // csr.hip
+    int slice_max_mb = 48;         // NGCF_SLICE_MAX_MB: largest table slice a d-sliced group may gather from
+    // spmm_swept.hip (plan)
+    int swept_waves = 0;           // NGCF_SWEPT_WAVES (LAB: 8)
+    int swept_cut = 4;             // NGCF_SWEPT_CUT: rows are cut at 1/cut of a wave task's share
+    int swept_no_moments = 0;      // NGCF_SWEPT_NO_MOMENTS
+    int swept_order_rows = 0;      // NGCF_SWEPT_ORDER=rows
+    int swept_debug = 0;           // NGCF_SWEPT_DEBUG: print the plan
+    int swept_window_kb = 0;       // NGCF_SWEPT_WINDOW_KB: 0 = by table size
+    // spmm_swept.hip (launch)
+    int swept_spin = 500;          // NGCF_SWEPT_SPIN
+    int swept_lead = -2;           // NGCF_SWEPT_LEAD: -2 = by table size, -1 = no synchronisation
+    int swept_sync_every = 1;      // NGCF_SWEPT_SYNC_EVERY
+    int swept_prio_kb = 256;       // NGCF_SWEPT_PRIO_KB
+    int swept_prio_graded = 1;     // NGCF_SWEPT_PRIO_GRADED
+    int swept_nt = 0;              // NGCF_SWEPT_NT (LAB)
+    int swept_merge = 0;           // NGCF_SWEPT_MERGE (LAB)
+    char swept_trace[480] = "";    // NGCF_SWEPT_TRACE (LAB): file prefix of the sweep-spread trace
+};
+extern NgcfOptions g_opts;                      // csr.hip
+const NgcfOptions &ngcf_opts();                 // csr.hip: reads the environment on first use
+
+
+// per-device state (function attributes, side streams) lives in small arrays indexed by the current device
+constexpr int kMaxDevices = 64;
+inline int current_device_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % kMaxDevices;
+}
+
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

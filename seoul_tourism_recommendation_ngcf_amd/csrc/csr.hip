@@ -13,7 +13,100 @@
 
 extern "C" const char *ngcf_last_error(void) { return g_err; }
 extern "C" const char *ngcf_target_arch(void) { return "gfx950"; }
-extern "C" int ngcf_version(void) { return 1; }
+extern "C" int ngcf_version(void) { return NGCF_ABI_VERSION; }   // the mirror refuses a library built from another header
+
+// ---------------------------------------------------------------------------------------------
+// options (common.h, NgcfOptions): the ONLY place of the library that reads the environment
+// ---------------------------------------------------------------------------------------------
+NgcfOptions g_opts;
+
+namespace {
+struct OptField {
+    const char *name;       // option name = environment variable without the NGCF_ prefix, lower case
+    int NgcfOptions::*i;
+    int64_t NgcfOptions::*l;
+};
+const OptField kOptFields[] = {
+    {"no_fork", &NgcfOptions::no_fork, nullptr},
+    {"no_slicing", &NgcfOptions::no_slicing, nullptr},
+    {"no_ldstab", &NgcfOptions::no_ldstab, nullptr},
+    {"no_panel_split", &NgcfOptions::no_panel_split, nullptr},
+    {"no_tail_table", &NgcfOptions::no_tail_table, nullptr},
+    {"no_pad_product", &NgcfOptions::no_pad_product, nullptr},
+    {"fork_min", nullptr, &NgcfOptions::fork_min},
+    {"tail_overlap", &NgcfOptions::tail_overlap, nullptr},
+    {"dense_direct", &NgcfOptions::dense_direct, nullptr},
+    {"dense_resident", &NgcfOptions::dense_resident, nullptr},
+    {"slice_max_mb", &NgcfOptions::slice_max_mb, nullptr},
+    {"swept_waves", &NgcfOptions::swept_waves, nullptr},
+    {"swept_cut", &NgcfOptions::swept_cut, nullptr},
+    {"swept_no_moments", &NgcfOptions::swept_no_moments, nullptr},
+    {"swept_order_rows", &NgcfOptions::swept_order_rows, nullptr},
+    {"swept_debug", &NgcfOptions::swept_debug, nullptr},
+    {"swept_window_kb", &NgcfOptions::swept_window_kb, nullptr},
+    {"swept_spin", &NgcfOptions::swept_spin, nullptr},
+    {"swept_lead", &NgcfOptions::swept_lead, nullptr},
+    {"swept_sync_every", &NgcfOptions::swept_sync_every, nullptr},
+    {"swept_prio_kb", &NgcfOptions::swept_prio_kb, nullptr},
+    {"swept_prio_graded", &NgcfOptions::swept_prio_graded, nullptr},
+    {"swept_nt", &NgcfOptions::swept_nt, nullptr},
+    {"swept_merge", &NgcfOptions::swept_merge, nullptr},
+};
+bool g_opts_read = false;
+}  // namespace
+
+// Defaults, then every NGCF_<NAME> variable that is set (a flag variable that is set but empty counts as 1).  Called once on
+// first use; tools call it again after changing os.environ.
+extern "C" int ngcf_options_from_env(void)
+{
+    NgcfOptions o;
+    for (const OptField &f : kOptFields) {
+        char var[64] = "NGCF_";
+        size_t n = strlen(var);
+        for (const char *p = f.name; *p && n + 1 < sizeof(var); ++p) var[n++] = (char)((*p >= 'a' && *p <= 'z') ? *p - 32 : *p);
+        var[n] = 0;
+        const char *e = getenv(var);
+        if (!e) continue;
+        const long long v = *e ? atoll(e) : 1;
+        if (f.i) o.*(f.i) = (int)(*e && (*e == '-' || (*e >= '0' && *e <= '9')) ? v : 1);
+        else o.*(f.l) = v;
+    }
+    if (const char *e = getenv("NGCF_SWEPT_ORDER")) o.swept_order_rows = !strcmp(e, "rows");
+    if (const char *e = getenv("NGCF_SWEPT_TRACE")) snprintf(o.swept_trace, sizeof(o.swept_trace), "%s", e);
+    g_opts = o;
+    g_opts_read = true;
+    return NGCF_OK;
+}
+
+const NgcfOptions &ngcf_opts()
+{
+    if (!g_opts_read) ngcf_options_from_env();
+    return g_opts;
+}
+
+extern "C" int ngcf_set_option(const char *name, int64_t value)
+{
+    if (!name) return fail(NGCF_ERR_ARG, "ngcf_set_option: null name");
+    (void)ngcf_opts();
+    for (const OptField &f : kOptFields)
+        if (!strcmp(f.name, name)) {
+            if (f.i) g_opts.*(f.i) = (int)value;
+            else g_opts.*(f.l) = value;
+            return NGCF_OK;
+        }
+    return fail(NGCF_ERR_ARG, "ngcf_set_option: unknown option '%s'", name);
+}
+
+extern "C" int ngcf_set_option_str(const char *name, const char *value)
+{
+    if (!name) return fail(NGCF_ERR_ARG, "ngcf_set_option_str: null name");
+    (void)ngcf_opts();
+    if (!strcmp(name, "swept_trace")) {
+        snprintf(g_opts.swept_trace, sizeof(g_opts.swept_trace), "%s", value ? value : "");
+        return NGCF_OK;
+    }
+    return fail(NGCF_ERR_ARG, "ngcf_set_option_str: unknown option '%s'", name);
+}
 
 
 static void free_plan(ngcf_csr *c)
@@ -124,10 +217,9 @@ __global__ void row_colrange_kernel(const int64_t *__restrict__ rowptr, const in
 // A row block is "sliceable" when one 32-float slice (128 B) of every row it gathers is at most 48 MiB: then the
 // hot part of the table slice lives in the XCD L2s while a slice-major launch walks it (measured on the user half
 // of C3: 2.33 ms sliced vs 2.98 ms unsliced; the 1 M-row user table gets slower sliced: 3.8 vs 3.46 ms).
-static int64_t slice_footprint_rows()   // NGCF_SLICE_MAX_MB: lab knob (C5-sized tables: slices that fit the 256 MiB Infinity Cache)
+static int64_t slice_footprint_rows()   // slice_max_mb: lab knob (C5-sized tables: slices that fit the 256 MiB Infinity Cache)
 {
-    const char *e = getenv("NGCF_SLICE_MAX_MB");
-    return ((int64_t)(e ? atoi(e) : 48) << 20) / 128;
+    return ((int64_t)ngcf_opts().slice_max_mb << 20) / 128;
 }
 #define kSliceFootprintRows slice_footprint_rows()
 

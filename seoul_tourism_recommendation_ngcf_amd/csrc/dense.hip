@@ -774,7 +774,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     // 50 vs 57 us at 256 -> 256, 97 vs 117 us at 8 192 x 512 -> 512; as soon as a CU gets a second workgroup the staged kernel
     // (two workgroups share a CU's LDS and matrix pipe; the direct kernel runs one wave per SIMD) wins clearly: 170 vs 277 us at
     // 12 288 rows, 1.08 vs 1.40 ms at 100 K.  NGCF_DENSE_DIRECT=0 / 2: never / at any row count.
-    const int direct_env = getenv("NGCF_DENSE_DIRECT") ? atoi(getenv("NGCF_DENSE_DIRECT")) : 1;
+    const int direct_env = ngcf_opts().dense_direct;
     const bool direct = direct_env && dop >= 256 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
                         n_rows > 0 && (n_rows <= 8192 || direct_env == 2);
     pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop,
@@ -787,15 +787,16 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
         // weights resident in LDS, no barriers (layer_dense_resident_kernel): large row counts at the 128-wide shapes, from two
         // tiles per wave on (128 -> 128, resident / staged us: 65 536 rows 59 / 59, 98 304 rows 95 / 85, 131 072 rows 96 / 104,
         // 262 144 rows 184 / 212, C3's 1.1 M rows 633 / 780; NGCF_DENSE_RESIDENT=0 keeps the staged kernel)
-        const int resident = getenv("NGCF_DENSE_RESIDENT") ? atoi(getenv("NGCF_DENSE_RESIDENT")) : 1;
+        const int resident = ngcf_opts().dense_resident;
         const int64_t lds_bytes = (int64_t)n_chunks * NGCF_KC * 128 * (int64_t)sizeof(float);
         if (resident && dop == 128 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
             lds_bytes <= 150 * 1024 && n_rows >= 2 * 32 * kResWaves * kResWGs) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            static bool attr_set[kMaxDevices] = {};      // the attribute is per device
+            const int dev_i = current_device_slot();
+            if (!attr_set[dev_i]) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
+                attr_set[dev_i] = true;
             }
             layer_dense_resident_kernel<<<dim3(kResWGs), kResWaves * 64, (size_t)lds_bytes, stream>>>(
                 LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc,
@@ -863,11 +864,8 @@ extern "C" int ngcf_layer_fused_f32(const ngcf_csr_t *c, const float *Eg, int64_
     // When the gathered rows are 16-byte aligned and padded, the columns up to the next multiple of 4 are simply multiplied along:
     // whatever they hold ends up in the padding columns of LE, which the dense half never reads (it selects zeros there).
     // (Reading them cannot fault: the 16-byte piece that holds the last column of a 16-byte aligned row is read whole.  The
-    // mirror's engine.spmm applies the same rule to the products of the training path, so both paths give the same bits.)
-    int d_sp = d_in;
-    if (d_in % 4 != 0 && c->nnz < ((int64_t)1 << 22) && ldEg % 4 == 0 && ldEg >= align_up(d_in, 4) && aligned16(Eg) &&
-        !getenv("NGCF_NO_PAD_PRODUCT"))
-        d_sp = (int)align_up(d_in, 4);
+    // mirror's engine.spmm asks the same function for the products of the training path, so both paths give the same bits.)
+    const int d_sp = ngcf_spmm_product_width(c, Eg, ldEg, d_in);
     int rc = ngcf_spmm_csr_f32(c, Eg, ldEg, d_sp, LE, ldLE, ws_spmm, spmm_ws, stream);
     if (rc != NGCF_OK) return rc;
     return ngcf_layer_dense_f32(LE, ldLE, Es, ldEs, c->n_rows, d_in, W1, b1, W2, b2, d_out, leaky, drop_p, drop_seed,

@@ -365,11 +365,11 @@ struct ForkState {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int device = -1;
 };
-static ForkState g_fork;
+static ForkState g_forks[kMaxDevices];          // one side stream + event pair per device
 
 static bool fork_ready(hipStream_t stream)
 {
-    if (getenv("NGCF_NO_FORK")) return false;
+    if (ngcf_opts().no_fork) return false;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
         (void)hipGetLastError();
@@ -377,6 +377,7 @@ static bool fork_ready(hipStream_t stream)
     }
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return false;
+    ForkState &g_fork = g_forks[dev % kMaxDevices];
     if (st != hipStreamCaptureStatusActive) {
         if (!g_fork.side) {
             ForkState f;
@@ -406,17 +407,18 @@ int launch_spmm(const SpmmArgs &a)
     const int64_t *heavy_seg_ptr = a.with_swept ? c->swept.out.heavy_seg_ptr : c->heavy_seg_ptr;
     const int64_t seg_blocks = (n_seg + 3) / 4;
     // d-slicing of the sliceable row groups needs 16-byte slices of 32 floats
-    const bool can_slice = VEC == 4 && a.d % 32 == 0 && a.d >= 64 && c->mode != 1 && !getenv("NGCF_NO_SLICING");
+    const bool can_slice = VEC == 4 && a.d % 32 == 0 && a.d >= 64 && c->mode != 1 && !ngcf_opts().no_slicing;
     // table-in-LDS kernel for the groups that gather from a few hundred rows: 16-byte pieces of 64-float slices
-    const bool can_ldstab = VEC == 4 && a.d % 4 == 0 && c->mode != 1 && !getenv("NGCF_NO_LDSTAB");
+    const bool can_ldstab = VEC == 4 && a.d % 4 == 0 && c->mode != 1 && !ngcf_opts().no_ldstab;
     bool seg_done = seg_blocks == 0;
     // under capture: segments (+ fix-up at the end) on the caller's stream, every group kernel on the side stream
     // (only where the halves are long enough to be worth a dependency edge - tools/fork_lab.py, Seoul-shaped forward as a hipGraph,
     // fork / one branch: d = 64 0.127 / 0.112 ms, 128 0.175 / 0.164, 256 0.247 / 0.312, 384 0.319 / 0.336, 512 0.370 / 0.395)
-    const int64_t fork_min = getenv("NGCF_FORK_MIN") ? atoll(getenv("NGCF_FORK_MIN")) : 200000000;   // lab knob (tools/fork_lab.py)
+    const int64_t fork_min = ngcf_opts().fork_min;   // lab knob (tools/fork_lab.py)
     const bool fork = seg_blocks > 0 && !a.with_swept && !c->groups.empty() && c->nnz * (int64_t)a.d >= fork_min &&
                       fork_ready(a.stream);
     hipStream_t gs = a.stream;
+    ForkState &g_fork = g_forks[current_device_slot()];
     if (fork) {
         HIP_TRY(hipEventRecord(g_fork.ev_fork, a.stream));
         HIP_TRY(hipStreamWaitEvent(g_fork.side, g_fork.ev_fork, 0));
@@ -440,11 +442,12 @@ int launch_spmm(const SpmmArgs &a)
             rpw = std::min<int64_t>(std::max<int64_t>((rpw + kLdsTabWaves - 1) / kLdsTabWaves * kLdsTabWaves, kLdsTabWaves), 64 * kLdsTabWaves);
             const int64_t rb = (n_rows_g + rpw - 1) / rpw;
             const size_t lds = ((size_t)n_tab + 1) * 256;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static bool attr_set[kMaxDevices] = {};      // the attribute is per device
+            const int dev_i = current_device_slot();
+            if (!attr_set[dev_i]) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_ldstab_kernel<4>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (kLdsTableRows + 1) * 256));
-                attr_set = true;
+                attr_set[dev_i] = true;
             }
             spmm_ldstab_kernel<4><<<dim3((unsigned)rb, (unsigned)n_slices), kLdsTabWaves * 64, lds, gs>>>(
                 c->rowptr, c->colidx, c->vals, grp.begin, grp.end, (int)rpw, c->seg_len, a.E, a.ldE, a.d, grp.col_lo, n_tab, a.out,
@@ -513,7 +516,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     // (measured at 130 on C3: 19.5 -> 18.7 ms per forward; with edge dropout the second pass over the entries costs
     // more than the scalar loads on the row-wise kernels, so there those products stay in one piece - they are split
     // only when the main panel then runs on the swept kernel)
-    if (rows_aligned && d > 4 && !getenv("NGCF_NO_PANEL_SPLIT")) {
+    if (rows_aligned && d > 4 && !ngcf_opts().no_panel_split) {
         int main = 0;
         if (d % 64 != 0 && d > 64 && swept_usable(c, ldE, d & ~63)) main = d & ~63;                // swept kernel + tail
         else if (d % 4 != 0 && dr.n == 0) main = d & ~3;                                           // float4 kernel + 1..3 columns
@@ -521,7 +524,7 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
             const int rc = spmm_dispatch(c, E, ldE, main, out, ldo, workspace, workspace_bytes, stream, dr);
             if (rc != NGCF_OK) return rc;
             const int tail = d - main;
-            if (tail <= 4 && dr.n == 0 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !getenv("NGCF_NO_TAIL_TABLE")) {
+            if (tail <= 4 && dr.n == 0 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !ngcf_opts().no_tail_table) {
                 // workspace: [partial sums ...            | T_in [n_cols] | T_out [n_rows]]
                 uintptr_t end = reinterpret_cast<uintptr_t>(workspace) + (uintptr_t)workspace_bytes;
                 float4 *Tout = reinterpret_cast<float4 *>((end - (uintptr_t)(c->n_rows * (int64_t)sizeof(float4))) & ~(uintptr_t)255);
@@ -581,6 +584,15 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
     else rc = launch_spmm<1, 64, 8, 1>(a);
     prof_mark(stream, 1);
     return rc;
+}
+
+// the width a product of this CSR should be run at when its output rows are padded (see ngcf_layer_fused_f32)
+extern "C" int ngcf_spmm_product_width(const ngcf_csr_t *c, const float *E, int64_t ldE, int d)
+{
+    if (c && d % 4 != 0 && c->nnz < ((int64_t)1 << 22) && ldE % 4 == 0 && ldE >= align_up(d, 4) && aligned16(E) &&
+        !ngcf_opts().no_pad_product)
+        return (int)align_up(d, 4);
+    return d;
 }
 
 extern "C" int ngcf_spmm_csr_f32(const ngcf_csr_t *c, const float *E, int64_t ldE, int d, float *LE, int64_t ldLE,

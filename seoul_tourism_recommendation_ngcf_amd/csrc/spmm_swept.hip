@@ -35,12 +35,6 @@ constexpr int kRowBits = 24;              // e_pack: column in bits 0..23, local
 constexpr int kColMask = (1 << kRowBits) - 1;
 constexpr int kLdsRows = 36 * 16;         // accumulator rows per workgroup (144 KiB of LDS, + one spare row per wave)
 
-int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 template <typename F>
 void parallel_for(int64_t n, F &&fn, int64_t min_parallel = 64)
 {
@@ -116,10 +110,12 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     if (!force && nnz < ((int64_t)1 << 22)) return NGCF_OK;          // small products are launch-bound, not L2-bound
     // workgroup shape: 16 waves x 36 rows.  (Round 1 ran the parts that need three or more row passes as 8 x 72: fewer,
     // longer wave tasks fetched 30 % less.  With the lag-driven wave priorities of the kernel 16 waves are faster there
-    // too - C3 user rows 1.60 vs 1.93 ms, profiles/r02_swept_lab.txt.)  NGCF_SWEPT_WAVES overrides (experiments, tests).
+    // too - C3 user rows 1.60 vs 1.93 ms, profiles/r02_swept_lab.txt.)  Lab builds (-DNGCF_LAB) keep the 8-wave shape behind the option swept_waves.
     const int64_t cap = (int64_t)kSweptWGs * kLdsRows;               // output rows resident in LDS at a time
     int waves = 16;
-    if (env_int("NGCF_SWEPT_WAVES", 0) == 8 || env_int("NGCF_SWEPT_WAVES", 0) == 16) waves = env_int("NGCF_SWEPT_WAVES", 0);
+#ifdef NGCF_LAB
+    if (ngcf_opts().swept_waves == 8) waves = 8;                      // the 8 x 72 shape is a lab instantiation
+#endif
     const int RW = kLdsRows / waves;
     const int64_t n_wave_slots = (int64_t)kSweptWGs * waves;
     if (!force) {
@@ -144,7 +140,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     for (;; ++n_rowpass) {
         n_tasks = n_rowpass * n_wave_slots;
         T = std::max<int64_t>(64, (nnz + n_tasks - 1) / n_tasks);
-        const int64_t Tp = std::max<int64_t>(64, T / std::max(2, env_int("NGCF_SWEPT_CUT", 4)));   // rows are cut well below a task's share
+        const int64_t Tp = std::max<int64_t>(64, T / std::max(2, ngcf_opts().swept_cut));   // rows are cut well below a task's share
         pieces.clear();
         heavy_row.clear();
         heavy_ptr.assign(1, 0);
@@ -176,7 +172,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     // coefficients of the task's cumulative-count deviation; the greedy gives each piece to the task of its bucket whose
     // moments it cancels best.  Simulated on the C3 item rows: spread (p5..p95) 2.9 -> 0.9 MiB, worst wave 4.6 -> 2.0 MiB.
     constexpr int kDealK = 8, kDealBucket = 256;
-    const bool balance_moments = !getenv("NGCF_SWEPT_NO_MOMENTS");
+    const bool balance_moments = !ngcf_opts().swept_no_moments;
     std::vector<float> mom;                                          // [piece][kDealK]
     if (balance_moments) {
         const int64_t span = (int64_t)col_hi - col_lo + 1;
@@ -263,7 +259,8 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     // 2) column windows and the slot layout of every (task, window) bucket
     // 8 MiB windows; 16 MiB when the table slice is 128 MiB or more (C3 item rows, lead 2: 1.58 vs 1.61 ms; on the 25 MiB
     // table of the user rows 8 MiB: 1.53 vs 1.84 ms)
-    int64_t win_kb = env_int("NGCF_SWEPT_WINDOW_KB", ((int64_t)col_hi - col_lo + 1) * kSW * 4 >= ((int64_t)128 << 20) ? 16384 : 8192);
+    int64_t win_kb = ngcf_opts().swept_window_kb > 0 ? ngcf_opts().swept_window_kb
+                                                     : (((int64_t)col_hi - col_lo + 1) * kSW * 4 >= ((int64_t)128 << 20) ? 16384 : 8192);
     if (win_kb < 16) win_kb = 16;
     const int32_t win_cols = (int32_t)std::max<int64_t>(64, win_kb * 1024 / (kSW * 4));
     const int64_t n_win = ((int64_t)col_hi - col_lo) / win_cols + 1;
@@ -284,7 +281,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     //  "cols"  : entries sorted by column, rounds filled greedily in that order with entries of distinct rows (an entry
     //            whose row is already in the round waits for the next one): the wave walks the window left to right
     // Either way the entries of one row never share a round (they are read-modify-written in LDS without atomics).
-    const bool by_cols = !(getenv("NGCF_SWEPT_ORDER") && !strcmp(getenv("NGCF_SWEPT_ORDER"), "rows"));   // default: cols
+    const bool by_cols = !ngcf_opts().swept_order_rows;   // default: cols
     struct Ent { int32_t col, lr; float v; };
     // schedule of one bucket: slot list (index into `ents`, -1 = empty), a multiple of kEPR long
     auto schedule_cols = [&](std::vector<Ent> &ents, std::vector<int32_t> &slots, std::vector<char> &done) {
@@ -412,7 +409,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
         dst[i] = r >= 0 ? (int32_t)(row_lo + r) : (int32_t)(-2 - (-1 - r));
         prow[i] = (int32_t)(row_lo + pieces[(size_t)task_piece[i]].src);   // the matrix row behind every accumulator row (edge dropout key)
     }
-    if (getenv("NGCF_SWEPT_DEBUG")) {
+    if (ngcf_opts().swept_debug) {
         int64_t mx = 0, mn = INT64_MAX;
         for (int64_t t = 0; t < n_tasks; ++t) {
             const int64_t s = tptr[(size_t)((t + 1) * n_win)] - tptr[(size_t)(t * n_win)];
@@ -682,10 +679,13 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
                 const int64_t idc = idx < end ? idx : end - 1;
                 int pk_l;
                 float v_l;
+#ifdef NGCF_LAB
                 if (nt_flags & 1) {              // the entry lists are read once: streaming loads, they should not displace table rows in L2
                     pk_l = __builtin_nontemporal_load(&e_pack[idc]);
                     v_l = __builtin_nontemporal_load(&e_val[idc]);
-                } else {
+                } else
+#endif
+                {
                     pk_l = e_pack[idc];
                     v_l = e_val[idc];
                 }
@@ -789,8 +789,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
                     if (drow != -1) {
                         float *o = drow >= 0 ? out + (int64_t)drow * ldo : partial + (int64_t)(-2 - drow) * dp;
                         const f32x4 res = *reinterpret_cast<const f32x4 *>(wacc + r * kSW + p * 4);
+#ifdef NGCF_LAB
                         if (nt_flags & 2) __builtin_nontemporal_store(res, reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4));
-                        else *reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4) = res;
+                        else
+#endif
+                        *reinterpret_cast<f32x4 *>(o + slice * kSW + p * 4) = res;
                     }
                 }
             }
@@ -805,7 +808,8 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
                  hipStream_t stream, const EdgeDrop &dr)
 {
     const ngcf_csr::Swept &w = c->swept;
-    const int max_spin = env_int("NGCF_SWEPT_SPIN", 500);                       // polls before a wave stops waiting for good
+    const NgcfOptions &o = ngcf_opts();
+    const int max_spin = o.swept_spin;                       // polls before a wave stops waiting for good
     // Inside a window a wave's entries are in ascending column order (plan, "cols" layout), so waves that enter a window
     // together walk the table left to right together and the live set is a few hundred KiB; the XCD-wide counters tick
     // once per 8 MiB window and a wave may be one window ahead - they only bound the drift.  bench.py on C3, same process:
@@ -815,19 +819,27 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
     // r02, with the graded wave priorities below (profiles/r02_swept_lab.txt, grid of window x lead x threshold): a table of
     // many windows wants lead 2 (C3 item rows, 16 windows: 1.50 vs 1.53 ms), a table of a few windows lead 1 (C3 user rows, 4
     // windows: 1.44 vs 1.46 ms); NGCF_SWEPT_LEAD overrides both (-1: no synchronisation at all)
-    const int lead_env = env_int("NGCF_SWEPT_LEAD", -2);
-    const int sync_k = std::max(1, env_int("NGCF_SWEPT_SYNC_EVERY", 1));       // windows per sweep step (lab knob)
+    const int lead_env = o.swept_lead;
+    const int sync_k = std::max(1, o.swept_sync_every);       // windows per sweep step (lab knob)
     // lag (KiB of table slice) behind the front of its workgroup beyond which a wave raises its priority; 0 = off
-    const unsigned prio_cols = (unsigned)std::max(0, env_int("NGCF_SWEPT_PRIO_KB", 256)) * 1024u / (kSW * 4);
+    const unsigned prio_cols = (unsigned)std::max(0, o.swept_prio_kb) * 1024u / (kSW * 4);
     // graded: priority 1 / 2 / 3 beyond 1x / 2x / 4x the threshold (C3 item rows 1.50 vs 1.61 ms against one step to 3)
-    const int prio_graded = env_int("NGCF_SWEPT_PRIO_GRADED", 1);
-    const int nt_flags = env_int("NGCF_SWEPT_NT", 0);                          // 1: streaming loads of the entry lists, 2: streaming stores of the rows
-    const char *trace = getenv("NGCF_SWEPT_TRACE");
+    const int prio_graded = o.swept_prio_graded;
+#ifdef NGCF_LAB
+    const int nt_flags = o.swept_nt;                                           // 1: streaming loads of the entry lists, 2: streaming stores of the rows
+    const char *trace = o.swept_trace[0] ? o.swept_trace : nullptr;
+#else
+    const int nt_flags = 0;
+#endif
     // consecutive parts of the same workgroup shape share a launch
     // one launch per part by default: taking both halves of C3 in one launch (NGCF_SWEPT_MERGE=1) was measured SLOWER (3.01-3.11
     // vs 2.96-2.98 ms per product, same box) - the workgroups that start the second part early gather from another table
     // and take L2 away from the stragglers of the first
-    const int max_parts = getenv("NGCF_SWEPT_MERGE") ? kMaxLaunchParts : 1;
+    #ifdef NGCF_LAB
+    const int max_parts = o.swept_merge ? kMaxLaunchParts : 1;
+#else
+    const int max_parts = 1;
+#endif
     for (size_t p0 = 0; p0 < w.parts.size();) {
         SweptLaunch L{};
         size_t p1 = p0;
@@ -841,26 +853,32 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
         const int waves = w.parts[p0].waves;
         HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
         unsigned long long *dbg = nullptr;
+#ifdef NGCF_LAB
         const size_t dbg_words = (size_t)kSweptWGs * waves * (2 * kDbgSamples + 2);
         if (trace) {
             HIP_TRY(hipMalloc(&dbg, dbg_words * 8));
             HIP_TRY(hipMemsetAsync(dbg, 0, dbg_words * 8, stream));
         }
+#endif
 #define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_, DROP_)                                                                                    \
     spmm_swept_kernel<RW_, NW_, DBG_, DROP_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, w.barrier,  \
                                                                                       max_spin, sync_k, prio_cols, prio_graded,    \
                                                                                       nt_flags, dbg, dr)
-        if (waves == 16) {
-            if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, true);
-            else if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true, false);
-            else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, false);
-        } else {
+#ifdef NGCF_LAB
+        if (waves == 8) {
             if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false, true);
             else if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, true, false);
             else NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false, false);
-        }
+        } else if (trace && dr.n == 0) {
+            NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true, false);
+        } else
+#endif
+        if (waves != 16) return fail(NGCF_ERR_ARG, "swept: the plan's workgroup shape (%d waves) is not compiled into this library", waves);
+        else if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, true);
+        else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, false);
 #undef NGCF_SWEPT_LAUNCH
         LAUNCH_CHECK();
+#ifdef NGCF_LAB
         if (trace) {     // lab only: host-synchronous dump, one file per launch
             const auto &p = w.parts[p0];
             std::vector<unsigned long long> h(dbg_words);
@@ -876,6 +894,7 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
                 fclose(f);
             }
         }
+#endif
         p0 = p1;
     }
     for (const auto &p : w.parts) {

@@ -235,6 +235,14 @@ class ShardedPropagation:
             raise RuntimeError("the sharded engine needs L = [[0, R], [R^T, 0]] (matrix.py:49-52)")
         if n_ue * 2 != rows.numel():
             raise RuntimeError("the sharded engine needs both triangles of L stored (matrix.py:51-52)")
+        if mode == "bipartite":
+            # the item rows of this scheme are formed as the transpose of the user rows: the lower triangle must BE that transpose
+            # (the reference's Laplacian is symmetric, matrix.py:51-62; a re-weighted or thinned lower triangle is not supported)
+            order = torch.sort(cols[:n_ue], stable=True).indices
+            if not (torch.equal(cols[:n_ue][order], rows[n_ue:]) and torch.equal(rows[:n_ue][order], cols[n_ue:])
+                    and torch.equal(vals[:n_ue][order], vals[n_ue:])):
+                raise RuntimeError("the bipartite exchange scheme needs a symmetric L (R^T stored as the exact transpose of R, "
+                                   "matrix.py:51-62); use mode='allgather' for anything else")
         cnt = row_counts(rows, U + I)
 
         def cut(user_lo, user_hi, item_lo, item_hi):

@@ -6,7 +6,6 @@ used for device memory and streams only; no tensor arithmetic of the hot path ha
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional, Sequence
 
 import torch
@@ -206,10 +205,7 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
         # the rule of ngcf_layer_fused_f32 (csrc/dense.hip), so that both forward paths produce the same bits: a width that is
         # not a multiple of 4 on a small (launch-bound) matrix is multiplied up to the next multiple of 4 when the gathered rows
         # are 16-byte aligned and padded - the extra columns land in the padding of `out`
-        d4 = (d + 3) // 4 * 4
-        if d4 != d and csr.nnz < (1 << 22) and E.stride(0) % 4 == 0 and E.stride(0) >= d4 and E.data_ptr() % 16 == 0 and \
-                not os.environ.get("NGCF_NO_PAD_PRODUCT"):
-            d = d4
+        d = int(lib.ngcf_spmm_product_width(csr._h, _ptr(E), _row_major_ld(E, "E"), d))
     ws = ws or Workspace()
     nb = csr.spmm_workspace_bytes(d)
     w = ws.get(nb, E.device)

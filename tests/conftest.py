@@ -32,3 +32,15 @@ def oracle_clib():
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     return ctypes.CDLL(path)
+
+
+@pytest.fixture
+def lib_options():
+    """Set tunables of libngcf_hip.so by name (ngcf_set_option) for one test; the environment's values come back afterwards."""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+
+    def set_(**kw):
+        for k, v in kw.items():
+            _lib.set_option(k, v)
+    yield set_
+    _lib.options_from_env()

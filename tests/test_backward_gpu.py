@@ -246,3 +246,33 @@ def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
     for k in grads[0]:
         scale = float(grads[1][k].abs().max()) + 1e-12
         np.testing.assert_allclose(grads[0][k].cpu().numpy(), grads[1][k].cpu().numpy(), atol=2e-5 * scale, rtol=1e-4, err_msg=k)
+
+
+def test_one_layer_model_at_embed_515_trains(dev):
+    """A one-layer model at the reference-legal embed_size 515 (515 -> [64]): the last layer's input is 515 wide, beyond the
+    512 columns the row scatter of the row-sparse path keeps in registers - the backward must take the dense path there and
+    give the same gradients as with the row-sparse path switched off."""
+    pkg = _pkg()
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    coo = pkg.graphs.synthetic_bipartite(900, 60, 9000, seed=3, device=dev)
+    num_dict = {"user": 900, "item": 60, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    B = 64
+    g = torch.Generator().manual_seed(9)
+    r = lambda hi: torch.randint(0, hi, (B,), generator=g).to(dev)  # noqa: E731
+    batch = dict(year=torch.full((B,), 18, device=dev), u_id=r(900), age=r(76), sex=r(2), month=r(13), day=r(32), dow=r(7),
+                 pos_item=r(60), neg_item=r(60))
+    grads = []
+    try:
+        for sparse in (True, False):
+            torch.manual_seed(2)
+            model = pkg.NGCF(515, [64], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, B, dev).to(dev)
+            ag.SPARSE_LAST_LAYER = sparse
+            u, p, n = model(node_flag=False, **batch)
+            pkg.BPR(0.025, B)(u, p, n).backward()
+            grads.append({k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None})
+    finally:
+        ag.SPARSE_LAST_LAYER = True
+    assert "w1_list.0.weight" in grads[0] and "user_embedding.weight" in grads[0]
+    for k in grads[0]:
+        scale = float(grads[1][k].abs().max()) + 1e-12
+        np.testing.assert_allclose(grads[0][k].cpu().numpy(), grads[1][k].cpu().numpy(), atol=2e-5 * scale, rtol=1e-4, err_msg=k)

@@ -316,11 +316,11 @@ def test_default_segment_length_follows_the_matrix_size(dev, oracle_clib):
 
 
 @pytest.mark.parametrize("d,order", [(64, "cols"), (128, "cols"), (256, "cols"), (128, "rows"), (576, "cols")])
-def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, monkeypatch):
+def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, lib_options):
     """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the L2-swept
     kernel (forced; both layouts of a wave's entry list inside a window) and the plain row-wise kernel must give the
     same product."""
-    monkeypatch.setenv("NGCF_SWEPT_ORDER", order)
+    lib_options(swept_order_rows=int(order == "rows"))
     pkg = _pkg()
     eng = pkg.engine
     coo = pkg.graphs.synthetic_bipartite(150000, 12000, 2600000, seed=33, device=dev)
@@ -352,12 +352,10 @@ def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, monkeypatch):
         np.testing.assert_allclose(swept[r].detach().cpu().numpy(), want.detach().cpu().numpy(), atol=ATOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize("waves", ["16", "8"])
-def test_spmm_swept_many_rows_several_row_passes(waves, dev, monkeypatch):
-    """More output rows than the chip's LDS holds at once: several row passes, in both workgroup shapes (16 waves x 36
-    rows and 8 x 72; NGCF_SWEPT_WAVES forces one).  Also a group with a handful of very long rows (cut into
-    strided pieces) and duplicate entries inside a row."""
-    monkeypatch.setenv("NGCF_SWEPT_WAVES", waves)
+def test_spmm_swept_many_rows_several_row_passes(dev):
+    """More output rows than the chip's LDS holds at once: several row passes (16 waves x 36 rows per workgroup; the 8 x 72
+    shape of round 1 is a lab instantiation, compiled only with -DNGCF_LAB).  Also a group with a handful of very long rows
+    (cut into strided pieces) and duplicate entries inside a row."""
     pkg = _pkg()
     eng = pkg.engine
     coo = pkg.graphs.synthetic_bipartite(330000, 3000, 2000000, seed=35, device=dev)
@@ -853,7 +851,7 @@ def test_odd_shapes_against_oracle(U, I, inter, d0, layers, B, dev):
 
 
 @pytest.mark.parametrize("d_in,d_out,mode", [(128, 128, "eval"), (130, 128, "hash"), (64, 100, "mask"), (144, 128, "last")])
-def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, mode, dev):
+def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, mode, dev, lib_options):
     """layer_dense_resident_kernel (weights resident in LDS, no barriers; taken from 131 072 rows on at 97..128 output columns)
     against layer_dense_kernel on the same inputs: the k order of every output element is the same, so carry and normalised
     block must agree bit for bit - in eval mode, with the hash dropout, with a host-drawn noise tensor, and without a carry."""
@@ -869,13 +867,12 @@ def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, m
     mask = (torch.rand((n, d_out), generator=g) > 0.3).float().to(dev) / 0.7 if mode == "mask" else None
     kw = dict(drop_p=0.3 if mode in ("hash", "mask") else 0.0, drop_seed=77 if mode == "hash" else 0, drop_mask=mask)
     outs = []
-    for resident in ("1", "0"):
-        os.environ["NGCF_DENSE_RESIDENT"] = resident
+    for resident in (1, 0):
+        lib_options(dense_resident=resident)
         carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
         norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]                # a column slice of a wider matrix
         eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
         outs.append((carry, norm.clone()))
-    del os.environ["NGCF_DENSE_RESIDENT"]
     assert torch.equal(outs[0][1], outs[1][1])
     if mode != "last":
         assert torch.equal(outs[0][0], outs[1][0])
@@ -888,7 +885,7 @@ def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, m
 @pytest.mark.parametrize("d_in,d_out,n,mode", [(515, 512, 5941, "eval"), (512, 512, 300, "hash"), (256, 256, 4099, "mask"),
                                               (130, 200, 1000, "last"), (260, 300, 33, "eval"), (8, 512, 64, "hash"),
                                               (256, 256, 40_003, "eval")])
-def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, mode, dev):
+def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, mode, dev, lib_options):
     """layer_dense_direct_kernel (256 / 512 output columns, operands straight from global memory, no LDS staging) against
     layer_dense_kernel on the same inputs: same k order per output element, so carry and normalised block agree bit for bit -
     eval mode, hash dropout, host-drawn noise, no carry, output widths below the padded width, partial last tiles."""
@@ -903,15 +900,12 @@ def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, 
     mask = (torch.rand((n, d_out), generator=g) > 0.3).float().to(dev) / 0.7 if mode == "mask" else None
     kw = dict(drop_p=0.3 if mode in ("hash", "mask") else 0.0, drop_seed=77 if mode == "hash" else 0, drop_mask=mask)
     outs = []
-    try:
-        for direct in ("2", "0"):
-            os.environ["NGCF_DENSE_DIRECT"] = direct
-            carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
-            norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]            # a column slice of a wider matrix
-            eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
-            outs.append((carry, norm.clone()))
-    finally:
-        del os.environ["NGCF_DENSE_DIRECT"]
+    for direct in (2, 0):
+        lib_options(dense_direct=direct)
+        carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
+        norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]            # a column slice of a wider matrix
+        eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
+        outs.append((carry, norm.clone()))
     assert torch.equal(outs[0][1], outs[1][1])
     if mode != "last":
         assert torch.equal(outs[0][0], outs[1][0])

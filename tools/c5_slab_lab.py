@@ -6,6 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
 from seoul_tourism_recommendation_ngcf_amd import dist as nd  # noqa: E402
+
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
 eng = pkg.engine
 dev = torch.device("cuda:0")
 U, I, W, rank, d = 10_000_000, 1_000_000, 8, 3, 256
@@ -36,6 +43,7 @@ def timeit(fn, n=5):
 
 for mb in ("48", "160", "300"):
     os.environ["NGCF_SLICE_MAX_MB"] = mb
+    _reload_options()
     for name, (r, c, vals, n_rows) in slabs.items():
         csr = eng.LaplacianCSR.from_coo(r, c, vals, n_rows, lay.P)
         for mode in (0, 1, 2):

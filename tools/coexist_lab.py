@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "tools", "coexist_lab.so")
-if os.environ.get("NGCF_NO_BUILD_LAB") != "1":
+if os.environ.get("NGCF_NO_BUILD_LAB") != "1" and os.environ.get("NGCF_NO_BUILD") != "1":   # never spawn a compiler under a profiler
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "coexist_lab.hip")])
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
 from seoul_tourism_recommendation_ngcf_amd import dist as nd  # noqa: E402

@@ -5,6 +5,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
+
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
 eng = pkg.engine
 dev = torch.device("cuda:0")
 
@@ -38,6 +45,7 @@ for n, d_in, d_out in SHAPES:
     res = {}
     for direct in ("2", "0"):
         os.environ["NGCF_DENSE_DIRECT"] = direct
+        _reload_options()
         res[direct] = t(lambda: eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, ws))
     fl = 4.0 * n * d_in * d_out
     print(f"n={n} {d_in}->{d_out}: direct {res['2']*1e3:.1f} us ({fl/res['2']/1e9:.1f} TF), staged {res['0']*1e3:.1f} us "

@@ -3,6 +3,13 @@ from n_tab table rows, 75 entries each."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import seoul_tourism_recommendation_ngcf_amd as pkg
+
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
 eng = pkg.engine
 dev = torch.device("cuda:0")
 
@@ -35,6 +42,7 @@ for n_rows in (5120, 200_000):
             for flag in ("", "1"):
                 if flag:
                     os.environ["NGCF_NO_LDSTAB"] = flag
+                    _reload_options()
                 else:
                     os.environ.pop("NGCF_NO_LDSTAB", None)
                 r[flag] = t(lambda: eng.spmm(csr, X, ws=ws))

@@ -5,6 +5,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
+
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
 eng = pkg.engine
 dev = torch.device("cuda:0")
 U, I, M = 1_000_000, 100_000, 50_000_000
@@ -45,20 +52,27 @@ for name, (r, c, v, nr) in parts.items():
     for (kb, every, order), waves, cut in [(k_, w_, c_) for k_ in windows for w_ in (os.environ.get("LAB_WAVES", "0").split(","))
                                     for c_ in os.environ.get("LAB_CUT", "4").split(",")]:
         os.environ["NGCF_SWEPT_WINDOW_KB"] = str(kb)
+        _reload_options()
         os.environ["NGCF_SWEPT_SYNC_EVERY"] = every
+        _reload_options()
         os.environ["NGCF_SWEPT_ORDER"] = order
+        _reload_options()
         os.environ["NGCF_SWEPT_WAVES"] = waves
+        _reload_options()
         os.environ["NGCF_SWEPT_CUT"] = cut
+        _reload_options()
         csr.set_mode(1)
         t0 = time.time()
         csr.set_mode(2)
         tb = time.time() - t0
         for lead in leads:
             os.environ["NGCF_SWEPT_LEAD"] = str(lead)
+            _reload_options()
             # launch-time knobs of the wave priorities (LAB_PRIO: lag thresholds in KiB, LAB_GRADED: 0 / 1)
             for prio in os.environ.get("LAB_PRIO", os.environ.get("NGCF_SWEPT_PRIO_KB", "512")).split(","):
                 for graded in os.environ.get("LAB_GRADED", "0").split(","):
                     os.environ["NGCF_SWEPT_PRIO_KB"], os.environ["NGCF_SWEPT_PRIO_GRADED"] = prio, graded
+                    _reload_options()
                     ms = timeit(lambda: eng.spmm(csr, E, out=out, ws=ws))
                     err = float((out - ref).abs().max())
                     print(f"{name}: swept window {kb:5d} KiB x{every} {order} waves {waves:>2s} cut T/{cut} lead {lead:2d} prio {prio:>4s} KiB "

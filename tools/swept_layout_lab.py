@@ -5,6 +5,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
+
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
 eng = pkg.engine
 dev = torch.device("cuda:0")
 U, I, M = 1_000_000, 100_000, 50_000_000
@@ -33,6 +40,7 @@ for name, (r, c, v, nr) in parts.items():
     csr = eng.LaplacianCSR.from_coo(r, c, v, nr, N)
     for kb in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "2048,4096,8192").split(",")]:
         os.environ["NGCF_SWEPT_WINDOW_KB"] = str(kb)
+        _reload_options()
         csr.set_mode(1)
         csr.set_mode(2)
         for ld in (64, 128, 256, 512):

@@ -16,6 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg  # noqa: E402
 
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
+
 eng = pkg.engine
 dev = torch.device("cuda:0")
 U, I, M = 1_000_000, 100_000, 50_000_000
@@ -105,8 +112,10 @@ for name, (r, c, v, nr) in parts.items():
     torch.cuda.synchronize()
     trace = os.path.join(out_dir, f"swept_trace_{name}")
     os.environ["NGCF_SWEPT_TRACE"] = trace
+    _reload_options()
     eng.spmm(csr, E, out=out, ws=ws)
     torch.cuda.synchronize()
     del os.environ["NGCF_SWEPT_TRACE"]
+    _reload_options()
     analyse(trace + ".part0", f"{name} rows")
     os.remove(trace + ".part0")

@@ -3,6 +3,13 @@ import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import seoul_tourism_recommendation_ngcf_amd as pkg
+
+
+def _reload_options():
+    """the library reads its NGCF_* variables once; re-read them after changing os.environ"""
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _lib.options_from_env()
+
 dev = torch.device("cuda:0")
 U, I, M = 1_000_000, 100_000, 50_000_000
 coo = pkg.graphs.synthetic_bipartite(U, I, M, seed=2603, device=dev)
@@ -23,6 +30,7 @@ model.eval()
 for split in ("1", ""):
     if split:
         os.environ["NGCF_NO_PANEL_SPLIT"] = split
+        _reload_options()
     else:
         os.environ.pop("NGCF_NO_PANEL_SPLIT")
     with torch.no_grad():
