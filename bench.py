@@ -43,6 +43,10 @@ WORKLOADS = {
     # BASELINE.json configs[0..1]: Seoul-shaped stand-in graph, full nn.Module forward incl. injection
     "c1": (5840, 100, 0, 65, (64, 64), 1801),
     "c2": (5840, 100, 0, 515, (512, 512), 1801),
+    # the reference's own TRAINING configuration (main.py:63-76, parsers.py defaults, experiment.py:45-58) on the Seoul-shaped
+    # stand-in: embed 65 -> [65, 65, 65], node dropout 0.3, message dropout [0.1]*3, batch 1024, Adam lr 1e-3, BPR wd 0.025,
+    # node_flag=True, model.train(); one step = forward + BPR + backward + optimizer step
+    "c1_train": (5840, 100, 0, 65, (65, 65, 65), 1801),
 }
 
 
@@ -62,6 +66,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--uniform-items", action="store_true", help="secondary line: no popularity skew")
     ap.add_argument("--hipgraph", action="store_true", help="Seoul-sized workloads: replay the forward as a hipGraph")
+    ap.add_argument("--dropout-mode", default="reference", choices=["reference", "device"],
+                    help="c1_train: where the dropout masks come from (NGCF.node_dropout_mode / mess_dropout_mode); the other "
+                         "mode is timed as a labelled secondary field")
     return ap.parse_args()
 
 
@@ -164,6 +171,147 @@ def cpu_baseline_full(coo, model, n_threads, seed=0):
             "seconds": dt}
 
 
+TRAIN_CFG = dict(embed=65, layers=(65, 65, 65), node_dropout=0.3, mess_dropout=(0.1, 0.1, 0.1), lr=1e-3, wd=0.025)
+
+
+def seoul_train_setup(pkg, dev, batch, mode, seed=1801):
+    """The reference's training configuration (main.py:63-76 + parsers.py defaults) on the Seoul-shaped stand-in graph, and one
+    step of experiment.py:45-58: model(node_flag=True) -> zero_grad -> BPR -> backward -> Adam.step, in train mode, with the
+    module's defaults otherwise (index check on)."""
+    slices = pkg.graphs.seoul_standin(dev, seed=seed)
+    nu, ni = slices[0]["n_user"], slices[0]["n_item"]
+    nd = {"user": nu, "item": ni, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(seed)
+    c = TRAIN_CFG
+    model = pkg.NGCF(c["embed"], list(c["layers"]), c["node_dropout"], list(c["mess_dropout"]), 1.0,
+                     [pkg.graphs.to_sparse_coo(x) for x in slices], nd, batch, dev).to(dev)
+    model.train()
+    model.node_dropout_mode = model.mess_dropout_mode = mode
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"])
+    crit = pkg.BPR(c["wd"], batch).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    ids = {k: torch.randint(0, hi, (batch,), generator=g).to(dev)
+           for k, hi in (("u_id", nu), ("pos_item", ni), ("neg_item", ni), ("age", 76), ("sex", 2), ("month", 13), ("day", 32), ("dow", 7))}
+    ids["year"] = torch.full((batch,), 18, device=dev)
+
+    def step():
+        u, p, n = model(node_flag=True, **ids)
+        opt.zero_grad()
+        loss = crit(u, p, n)
+        loss.backward()
+        opt.step()
+        return loss
+    return model, step, slices[0], ids
+
+
+def time_train_steps(step, steps, warmup):
+    """(ms per step wall clock with a sync on both sides, ms per step the host spent issuing it - i.e. without the final wait)."""
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(loss).item(), "non-finite loss"
+    return el / steps * 1e3, t_issue / steps * 1e3, float(loss)
+
+
+def cpu_train_baseline(coo_slices_cpu, n_user, model, ids, batch, n_threads, steps=5):
+    """The reference's training step on the host (oracle/ngcf_oracle.py, the torch CPU ops of NGCF.py:102-156 + bprloss.py with
+    torch autograd and torch.optim.Adam - what experiment.py:45-58 runs on a CPU device), same graph, same initial state."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ngcf_oracle as orc
+    c = TRAIN_CFG
+    torch.set_num_threads(n_threads)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if k.startswith(("w1_list", "w2_list", "item_emb", "user_emb"))}
+    feats = {"age": sd["age_emb.weight"], "sex": sd["sex_emb.weight"], "month": sd["month_emb.weight"],
+             "day": sd["day_emb.weight"], "dow": sd["dow_emb.weight"]}
+    n = len(c["layers"])
+    opt = torch.optim.Adam(list(leaves.values()), lr=c["lr"])
+    ids = {k: v.cpu() for k, v in ids.items()}
+    L = coo_slices_cpu
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc.feature_inject_torch(leaves["user_embedding.weight"], feats, ids["u_id"], ids["age"], ids["sex"], ids["month"],
+                                     ids["day"], ids["dow"], 1.0)
+        all_E = orc.propagate_torch(L, leaves["user_embedding.weight"], leaves["item_embedding.weight"],
+                                    [leaves[f"w1_list.{k}.weight"] for k in range(n)], [leaves[f"w1_list.{k}.bias"] for k in range(n)],
+                                    [leaves[f"w2_list.{k}.weight"] for k in range(n)], [leaves[f"w2_list.{k}.bias"] for k in range(n)],
+                                    mess_dropout=list(c["mess_dropout"]), training=True, node_dropout=c["node_dropout"], node_flag=True)
+        u, p, ng = orc.gather_torch(all_E, n_user, ids["u_id"], ids["pos_item"], ids["neg_item"])
+        opt.zero_grad()
+        loss = orc.bpr_torch(u, p, ng, c["wd"], batch)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return dt, float(loss.detach())
+
+
+def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5):
+    """One labelled measurement of the reference's training step in one dropout mode."""
+    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode)
+    ms, ms_issue, loss = time_train_steps(step, steps, warmup)
+    n_layer = len(TRAIN_CFG["layers"])
+    return {"ms_per_step": ms, "host_issue_ms_per_step": ms_issue, "value": n_layer * coo["nnz"] / (ms * 1e-3), "unit": "edges/s",
+            "loss": loss, "steps": steps, "dropout_mode": mode,
+            "note": f"main.py:63-76 / experiment.py:45-58 on the Seoul-shaped stand-in: embed {TRAIN_CFG['embed']} -> {list(TRAIN_CFG['layers'])}, "
+                    f"node dropout {TRAIN_CFG['node_dropout']}, message dropout {list(TRAIN_CFG['mess_dropout'])}, batch {batch}, Adam lr "
+                    f"{TRAIN_CFG['lr']}, BPR wd {TRAIN_CFG['wd']}, node_flag=True, train mode; step = forward + BPR + backward + Adam.step; "
+                    f"masks: {'torch CPU generator, drawn where the reference draws them' if mode == 'reference' else 'counter hash inside the kernels'}"}
+
+
+def main_train(args, pkg, dev):
+    """--workload c1_train: the reference's own training step (forward + BPR + backward + Adam) on the Seoul-shaped stand-in."""
+    mode = args.dropout_mode
+    model, step, coo, ids = seoul_train_setup(pkg, dev, args.batch, mode)
+    ms, ms_issue, loss = time_train_steps(step, args.steps, args.warmup)
+    n_layer = len(TRAIN_CFG["layers"])
+    out = {
+        "metric": "NGCF 3-layer forward: propagated edges/sec + achieved HBM GB/s, d=128",
+        "value": n_layer * coo["nnz"] / (ms * 1e-3), "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "host_issue_ms_per_step": ms_issue, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c1_train: the reference's training step (main.py:63-76, experiment.py:45-58) on the Seoul-shaped stand-in, "
+                               f"{coo['n_user']} users x {coo['n_item']} items, nnz(L)={coo['nnz']}, embed {TRAIN_CFG['embed']} -> "
+                               f"{list(TRAIN_CFG['layers'])}, node dropout {TRAIN_CFG['node_dropout']} ({mode} mode), message dropout "
+                               f"{list(TRAIN_CFG['mess_dropout'])}, batch={args.batch}, Adam lr {TRAIN_CFG['lr']}, BPR wd {TRAIN_CFG['wd']}; "
+                               "step = forward + BPR + backward + optimizer step (NOT the headline metric's forward-only step)",
+                   "n_user": coo["n_user"], "n_item": coo["n_item"], "nnz_L": coo["nnz"], "d": TRAIN_CFG["embed"], "n_layers": n_layer,
+                   "batch": args.batch, "dropout_mode": mode, "parallelism": "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                     "note": "launch-bound: the working set (E 1.5 MB, CSR 7 MB) is cache-resident and a step is ~100 launches of a few "
+                             "microseconds; an HBM fraction is not meaningful here (SURVEY 8d)"},
+        "loss": loss,
+    }
+    if not args.no_secondary:
+        other = "device" if mode == "reference" else "reference"
+        try:
+            out["secondary"] = {f"dropout_mode_{other}": train_secondary(pkg, dev, args.batch, other, args.steps, args.warmup)}
+        except Exception as exc:  # noqa: BLE001
+            out["secondary"] = {f"dropout_mode_{other}": {"error": repr(exc)[:300]}}
+    if not args.no_cpu_baseline:
+        N = coo["n_user"] + coo["n_item"]
+        L = torch.sparse_coo_tensor(torch.stack([coo["rows"], coo["cols"]]).cpu(), coo["vals"].cpu(), (N, N))
+        torch.manual_seed(1801)
+        fresh, _, _, _ = seoul_train_setup(pkg, dev, args.batch, mode)          # same initial state as the timed model had
+        dt, closs = cpu_train_baseline(L, coo["n_user"], fresh, ids, args.batch, host_cores())
+        out["cpu_baseline"] = {"value": n_layer * coo["nnz"] / dt, "unit": "edges/s", "cores": host_cores(), "kind": "port",
+                               "cpu_model": cpu_model(), "seconds": dt, "loss": closs,
+                               "sample": f"the same training step on the host: oracle/ngcf_oracle.py (torch CPU ops of NGCF.py:102-156 + "
+                                         f"bprloss.py) with torch autograd and torch.optim.Adam, median of 5 steps after 1, {dt * 1e3:.1f} ms "
+                                         f"per step at {host_cores()} threads, torch {torch.__version__}"}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
 def edges_per_step_of(n_layer, nnz):
     return n_layer * nnz
 
@@ -197,6 +345,10 @@ def main():
     from seoul_tourism_recommendation_ngcf_amd import _lib, dist as ngcf_dist
     lib = _lib.load()
 
+    if args.workload == "c1_train":
+        if world != 1:
+            raise SystemExit("c1_train is a single-GPU configuration")
+        return main_train(args, pkg, dev)
     n_user, n_item, n_inter, d0, layers, seed = WORKLOADS[args.workload]
     seoul = args.workload in ("c1", "c2")
     full_forward = d0 % 5 == 0                                # a width the reference accepts: time the whole NGCF.forward
@@ -394,6 +546,16 @@ def main():
                 del fwd_s, ms
             except Exception as exc:  # noqa: BLE001
                 secondary[f"{wl}_seoul_shaped_hipgraph"] = {"error": repr(exc)[:300]}
+
+    if world == 1 and not seoul and not args.no_secondary:
+        # the reference's own training step (main.py:63-76, experiment.py:45-58) on the Seoul-shaped stand-in, in both dropout modes
+        torch.set_grad_enabled(True)
+        for mode in ("reference", "device"):
+            try:
+                secondary[f"c1_train_{mode}_masks"] = train_secondary(pkg, dev, args.batch, mode)
+            except Exception as exc:  # noqa: BLE001
+                secondary[f"c1_train_{mode}_masks"] = {"error": repr(exc)[:300]}
+        torch.set_grad_enabled(False)
 
     swept = [csr.swept_rows] if world == 1 else sh.swept_rows()
     kernel_name = ("spmm_swept_kernel (one L.E product: a launch per row group + fix-up)" if all(swept) else

@@ -89,8 +89,32 @@ int ngcf_csr_plan(ngcf_csr_t *csr, int32_t seg_len, void *stream);
  * (tests); 3 = L2-swept kernel on the row groups where its host-side plan expects enough L2 re-use to pay, the
  * row-wise kernels on the rest - meant for long-lived matrices (the Laplacians of `lap_list`): building the plan
  * costs a host pass over the entries and as much device memory again as the CSR.  Calls whose width is not a
- * multiple of 64, that use edge dropout, or whose table spans more than 4 GiB use the row-wise kernels anyway. */
+ * multiple of 64, that use edge dropout, or whose table spans more than 4 GiB use the row-wise kernels anyway.
+ * A CSR with swept parts carries ONE block of sweep counters: products of the same CSR must not run concurrently on two
+ * streams (results stay correct - the counters only pace the sweep - but both products lose their L2 re-use). */
 int ngcf_csr_set_mode(ngcf_csr_t *csr, int mode, void *stream);
+/*
+ * Thinned copy of a CSR, made on the device: *dst keeps, in src's order, every stored entry e of `src` with
+ * keep[map ? map[e] : e] != 0 (`keep`: device uint8, one flag per entry of the matrix the flags were drawn for; `map`: device
+ * int32[src nnz] or NULL = identity).  This is the reference's per-layer `sparse_dropout` (NGCF.py:93-100,124-126: a COO tensor
+ * rebuilt from `indices[:, mask]`, values not rescaled) as one stream compaction: no host round trip, no synchronisation, and
+ * no allocation after the first call - pass the previous step's object back in *dst and its buffers are re-used (*dst == NULL:
+ * a new object, sized for all of src's entries).  `nnz_kept`: the number of set flags if the caller knows it (it drew the
+ * mask), else -1: ngcf_csr_nnz(*dst) is then an upper bound.  The copy runs on the row-wise kernels (mode 0) with src's
+ * segment structure and row groups and BORROWS them: `src` must outlive `*dst`.
+ * ngcf_csr_filter_pos(dst): device int32[src nnz + 1], pos[e] = kept entries before e (the new position of a kept entry).
+ */
+int ngcf_csr_filter(const ngcf_csr_t *src, const uint8_t *keep, const int32_t *map, int64_t nnz_kept, ngcf_csr_t **dst,
+                    void *stream);
+const int32_t *ngcf_csr_filter_pos(const ngcf_csr_t *dst);
+/*
+ * Entry map of a thinned transpose.  L^T is thinned with the flags drawn for L through map[j] = position in L of entry j of
+ * L^T; after both were filtered, the next layer needs the same map between the two thinned matrices:
+ * map_out[pos_t[j]] = pos_l[map[j]] for every kept j, with pos_t = ngcf_csr_filter_pos(dst_t), pos_l = that of the thinned L.
+ * n_src_entries: entries of the transpose that was filtered into dst_t.
+ */
+int ngcf_csr_filter_remap(const ngcf_csr_t *dst_t, const uint8_t *keep, const int32_t *map, int64_t n_src_entries,
+                          const int32_t *pos_l, int32_t *map_out, void *stream);
 void ngcf_csr_free(ngcf_csr_t *csr);
 int64_t ngcf_csr_nnz(const ngcf_csr_t *csr);
 int64_t ngcf_csr_n_rows(const ngcf_csr_t *csr);
@@ -232,38 +256,39 @@ int ngcf_bpr_fused_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, c
                        void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- backward pass (`loss.backward()` of experiment.py:57; driven by autograd.py) -------------- */
-/* The two plain GEMMs of a layer's backward (dM.[W1|W2] and dM^T.[S|P]) are library GEMMs issued by the host
- * mirror; the entry points below are everything around them.  L^T.dLE re-uses ngcf_spmm_csr_f32 on the CSR of L^T. */
+/* Everything `loss.backward()` runs: no library GEMM at any width.  L^T.dLE re-uses ngcf_spmm_csr_f32 on the CSR of L^T. */
 /* du/dp/dn of the BPR loss (bprloss.py:15-22) times the upstream scalar *grad_out (device). */
 int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp, const float *n, int64_t Bn, int D,
                           float weight_decay, float batch_size, const float *grad_out, float *du, float *dp,
                           float *dn, void *stream);
-/* Backward of the row gathers (NGCF.py:151-155): G[row_off + idx[b], :] += g[b, :]; duplicates add up. */
-int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, int64_t B, int64_t row_off,
-                              int64_t n_idx_rows, const float *g, int64_t ldg, void *stream);
+/* Backward of the row gathers (NGCF.py:151-155): the gradient rows g [M, d] of the gathered positions, summed per distinct row
+ * of all_E in a fixed order: out[r, :] = sum of g[order[j], :] for j in [segptr[r], segptr[r+1]), in that order (`order`: the
+ * gathered positions sorted by row, stable - duplicates add up in batch order; int64 device arrays).  No atomics. */
+int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr, int64_t n_seg,
+                              float *out, int64_t ldo, void *stream);
 /* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block; NULL = zero:
  * the rows no gather touched), dC (gradient of the carry from the next layer, may be NULL; not both) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,
                            int64_t n_rows, int d, float leaky_slope, float drop_p, uint64_t drop_seed,
                            const float *drop_mask, int64_t ld_mask, const int64_t *row_ids, float *dM, int64_t ldm, void *stream);
 /* (row_ids: NULL, or the matrix rows the n_rows compacted rows stand for - they index the hash stream of device-mode dropout) */
-/* out[c, :] += v * X[i, :] for every stored entry (rows[i], c, v) of `csr`: L^T . X for a row-sparse X given by its n_sel
- * non-zero rows (float atomics; `out` must hold the other summands or zeros).  max_row_len: longest row of the CSR (sizes the
- * grid).  drop_p / seeds: device-side node dropout as in ngcf_spmm_csr_dropout_f32 (entry numbers = positions in `csr`). */
-int ngcf_spmm_scatter_rows_f32(const ngcf_csr_t *csr, const int64_t *rows, int64_t n_sel, int64_t max_row_len, const float *X,
-                               int64_t ldx, int d, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
-                               void *stream);
+/* out = init + L^T . X for a ROW-SPARSE X (the last layer's backward: dLE is non-zero on the <= 3 B gathered rows only).
+ * csr_t: the CSR of L^T ([N, N]); slot: device int32[N], slot[r] = row of the compact X [R, d] that holds matrix row r, or -1
+ * (zero row); init: compact [R, d] or NULL, added to the rows with slot >= 0 (the direct part of the gradient).
+ * out[c, :] = (slot[c] >= 0 ? init[slot[c], :] : 0) + sum over the stored entries (c, r, v) of csr_t with slot[r] >= 0 of
+ * v * X[slot[r], :], in entry order: a fixed summation order, no atomics; every row of out [N, d] is written.
+ * drop_p / seeds: device-side node dropout as in ngcf_spmm_csr_dropout_f32 (csr_t is walked as the transpose).
+ * workspace: ngcf_spmm_workspace_bytes(csr_t, min(d, 512)) bytes (partial sums of the cut rows). */
+int ngcf_spmm_t_rows_f32(const ngcf_csr_t *csr_t, const int32_t *slot, const float *X, int64_t ldx, int d, const float *init,
+                         int64_t ldi, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
+                         void *workspace, int64_t workspace_bytes, void *stream);
 /* Input gradients of a layer's dense half in one MFMA kernel: dS = dM.W1, dP = dM.W2 (never stored), dLE = dS + dP*E,
- * dE_direct = dS + dP*LE (NGCF.py:131-136 differentiated).  dM: [n_rows, d_out] with 16-byte aligned rows padded to a
- * multiple of 4 floats; W1, W2: [d_out, d_in] row-major (nn.Linear.weight); LE, E, dLE, dE: [n_rows, d_in]. */
+ * dE_direct = dS + dP*LE (NGCF.py:131-136 differentiated).  dM: [n_rows, d_out], any d_out >= 1 (65 in the reference's own
+ * configuration), with 16-byte aligned rows padded to a multiple of 4 floats (the padding is never used); W1, W2: [d_out, d_in] row-major (nn.Linear.weight); LE, E, dLE, dE: [n_rows, d_in]. */
 int64_t ngcf_layer_bwd_input_workspace_bytes(int d_out);
 int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_rows, int d_out, const float *W1, const float *W2,
                              int d_in, const float *LE, int64_t ldLE, const float *E, int64_t ldE, float *dLE, int64_t ldd,
                              float *dE, int64_t lde, void *workspace, int64_t workspace_bytes, void *stream);
-/* SP[n_rows, 2d] = [LE + E | LE * E], the forward GEMM operand (NGCF.py:131-136), needed for dW1/dW2. */
-int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ldE, int64_t n_rows, int d, float *SP,
-                       void *stream);
-/* dSP[n_rows, 2d] = dM.[W1 | W2]  ->  dLE = dS + dP*E,  dE_direct = dS + dP*LE  (both [n_rows, d] contiguous). */
 /* weight gradients of one layer on the fp32 matrix cores: gW [d_out, 2 d_in] row-major,
  * gW[:, :d_in] = dM^T . (LE + E) (W1, NGCF.py:131-133), gW[:, d_in:] = dM^T . (LE * E) (W2, NGCF.py:135-136);
  * d_in, d_out <= 128 per call (the host tiles wider layers over column blocks of dM, LE and E).  Fixed
@@ -274,8 +299,6 @@ int64_t ngcf_bwd_weight_workspace_bytes(void);
 int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
                               int64_t n_rows, int d_in, int d_out, float *gW, float *gb, void *workspace,
                               int64_t workspace_bytes, void *stream);
-int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
-                               int64_t n_rows, int d, float *dLE, int64_t ld_dLE, float *dE, int64_t ld_dE, void *stream);
 /* out[r, 0:d] += add[r, 0:d] */
 int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream);
 
@@ -312,6 +335,38 @@ int ngcf_shard_plan(const int64_t *rowptr_host, int64_t row_begin, int64_t row_e
 int ngcf_allgather_rows(void *nccl_comm, const float *send, float *recv, int64_t rows_per_rank, int d, void *stream);
 /* number of ranks of the communicator (host call) */
 int ngcf_comm_size(void *nccl_comm, int *n_ranks);
+
+/*
+ * CU-free exchange between the ranks of one node (r03): copy engines move the bytes, host threads do the waiting, no kernel of
+ * the exchange ever occupies a CU - the L2-swept SpMM keeps the chip to itself while the previous step's rows travel.
+ * Every rank owns one exchange buffer; its producers write the rows the others need into it; the others PULL:
+ *   ngcf_p2p_create   allocate the buffer (current device) and map the node's shared sequence words (POSIX shm `shm_name`, the
+ *                     same name on every rank, unique per job)
+ *   ngcf_p2p_handle   64-byte IPC handle of the buffer; the caller all-gathers the handles (host, any transport)
+ *   ngcf_p2p_connect  open the peers' buffers (handles: world x 64 bytes, rank-major)
+ *   ngcf_p2p_publish  on `stream`: everything enqueued so far is finished and visible to other devices when peers see `seq`
+ *   ngcf_p2p_pull     host-wait (bounded) for rank `peer`'s `seq` in `slot`, then enqueue dst <- peer buffer[src_off, +bytes)
+ *                     on this rank's copy stream for that peer (device-to-device: an SDMA engine across xGMI)
+ *   ngcf_p2p_ack / ngcf_p2p_wait_acks   the reverse notice: a producer overwrites a region only after all peers have read it
+ *   ngcf_p2p_fence    later copies start only after what `stream` holds now (the last readers of their destinations)
+ *   ngcf_p2p_join     `stream` waits (stream dependency, no kernel) for every copy enqueued since the last join
+ * `seq` must grow from call to call per slot (64 slots).  A wait that exceeds timeout_ms fails with NGCF_ERR_HIP.
+ * ngcf_sum_slots_f32: out = slots[0] + slots[1] + ... (fixed order): the owner's side of a reduce-scatter done with pulls.
+ */
+typedef struct ngcf_p2p ngcf_p2p_t;
+int ngcf_p2p_create(int rank, int world, int64_t bytes, const char *shm_name, ngcf_p2p_t **out);
+void ngcf_p2p_destroy(ngcf_p2p_t *p2p);
+int ngcf_p2p_handle(ngcf_p2p_t *p2p, void *handle64_host);
+int ngcf_p2p_connect(ngcf_p2p_t *p2p, const void *handles_host);
+void *ngcf_p2p_local(ngcf_p2p_t *p2p);
+int64_t ngcf_p2p_bytes(const ngcf_p2p_t *p2p);
+int ngcf_p2p_publish(ngcf_p2p_t *p2p, int slot, uint64_t seq, void *stream);
+int ngcf_p2p_pull(ngcf_p2p_t *p2p, int peer, int slot, uint64_t seq, int64_t src_off, void *dst, int64_t bytes, double timeout_ms);
+int ngcf_p2p_ack(ngcf_p2p_t *p2p, int peer, int slot, uint64_t seq);
+int ngcf_p2p_wait_acks(ngcf_p2p_t *p2p, int slot, uint64_t seq, double timeout_ms);
+int ngcf_p2p_fence(ngcf_p2p_t *p2p, void *stream);
+int ngcf_p2p_join(ngcf_p2p_t *p2p, void *stream);
+int ngcf_sum_slots_f32(const float *slots, int64_t slot_stride, int n_slots, int64_t n, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,9 @@ class NGCF(nn.Module):
 
         # engine state (not part of the state_dict)
         self._csr_cache = {}
+        self._filt = {}                  # thinned CSRs of the reference-mode node dropout, re-used from step to step
+        self._filt_maps = {}             # entry maps of their transposes
+        self._row_sorted = {}            # id(lap_list entry) -> its COO rows are non-decreasing
         self._ws = _eng.Workspace()
         self._carry: List[Optional[torch.Tensor]] = [None, None]
         self._scratch: Optional[torch.Tensor] = None
@@ -92,6 +95,15 @@ class NGCF(nn.Module):
         self.all_users_emb = None
         self.all_items_emb = None
         self._all_E = None
+        # Inference calls (eval mode, no autograd, node_flag=False) of launch-bound sizes are captured into a hipGraph on first
+        # use and replayed afterwards (`_forward_graphed`): unchanged callers (experiment.py:66-119, demo.py:213-236) get the
+        # replay speed without knowing about it.  `auto_graph = False` switches it off.
+        self.auto_graph = True
+        self.auto_graph_max_bytes = 64 << 20     # all_E above this size: the forward is not launch-bound, nothing to gain
+        self.index_check_every = 16              # graph replays: read the (sticky) status word every k-th call; 1 = every call
+        self._graphs = {}                        # (sizes, year slice, parameter addresses) -> GraphedForward, most recent last
+        self._graph_calls = 0
+        self._graph_seen = set()
 
     # ------------------------------------------------------------------------------------
     # engine plumbing
@@ -153,16 +165,19 @@ class NGCF(nn.Module):
         csr = self._csr_cache.get(key)
         if csr is None:
             rows, cols, vals = self._sorted_coo(L, dev)
-            csr = self._transposed_csr(torch.stack([rows, cols]), vals)
+            csr, order = self._transposed_csr(torch.stack([rows, cols]), vals)
             csr.set_mode(_spmm_mode())
             self._csr_cache[key] = csr
+            # entry j of L^T is entry order[j] of L: lets the reference-mode node dropout thin L^T with the flags drawn for L
+            self._csr_cache[("Tmap",) + key[1:]] = order.to(torch.int32) if order.numel() < 2 ** 31 - 1 else None
         return csr
 
-    def _transposed_csr(self, idx: torch.Tensor, val: torch.Tensor) -> "_eng.LaplacianCSR":
-        """CSR of the transpose (the device-mode edge dropout is keyed by (row, column) of L: no entry map is needed)."""
+    def _transposed_csr(self, idx: torch.Tensor, val: torch.Tensor):
+        """CSR of the transpose (the device-mode edge dropout is keyed by (row, column) of L: no entry map is needed) and the
+        position in L of every entry of L^T."""
         N = self.n_user + self.n_item
         order = torch.sort(idx[1], stable=True).indices          # by column = row of L^T, original order kept inside
-        return _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N)
+        return _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N), order
 
     def _layer_params(self):
         return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],
@@ -179,18 +194,42 @@ class NGCF(nn.Module):
         dev = self._dev()
         N = self.n_user + self.n_item
         widths = [self.emb_size] + list(self.weight_size)
-        csrs, kept, masks = [], [], []
+        csrs, flags, masks = [], [], []
         if node_ref:
             L = self.lap_list[year_idx]
-            idx = L._indices().to(dev)
-            val = L._values().to(device=dev, dtype=torch.float32)
+            row_sorted = self._row_sorted.get(id(L))
+            if row_sorted is None:
+                r = L._indices()[0]
+                row_sorted = self._row_sorted[id(L)] = bool(r.numel() < 2 or not bool((r[1:] < r[:-1]).any()))
+            if not row_sorted:           # entry numbers of the stored COO differ from the CSR's: the rebuild path (matrix.py emits sorted rows)
+                return self._reference_draws_rebuild(year_idx, drop, mess_ref)
+            src = self.laplacian_csr(year_idx)
+        # torch's CPU bernoulli spreads a draw over every thread it may use; on a many-core host (a GPU node's 256 CPUs) that is
+        # slower than a few threads by an order of magnitude (26 ms instead of ~3 ms for 0.9 M flags).  The numbers drawn do not
+        # depend on the thread count (each chunk skips ahead in one stream), so the draws run on at most 16 threads.
+        n_thr = torch.get_num_threads()
+        if n_thr > 16:
+            torch.set_num_threads(16)
+        try:
+            return self._reference_draws_body(year_idx, node_ref, drop, mess_ref, src if node_ref else None, dev, N, widths)
+        finally:
+            if n_thr > 16:
+                torch.set_num_threads(n_thr)
+
+    def _reference_draws_body(self, year_idx, node_ref, drop, mess_ref, src, dev, N, widths):
+        csrs, flags, masks = [], [], []
         for k in range(self.n_layer):
             if node_ref:
-                mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
-                                                   p=self.node_dropout, training=True).type(torch.bool).to(dev)
-                idx, val = idx[:, mask], val[mask]
-                csrs.append(_eng.LaplacianCSR.from_coo(idx[0], idx[1], val, N, N))
-                kept.append((idx, val))
+                # one flag per entry of the matrix as the previous layers left it (cumulative, NGCF.py:126); the thinned CSR is a
+                # device compaction of the previous one into buffers this module keeps from step to step (ngcf_csr_filter)
+                keep = torch.nn.functional.dropout(torch.ones(src.nnz, dtype=torch.float64), p=self.node_dropout,
+                                                   training=True).type(torch.bool)
+                n_kept = int(keep.sum())
+                keep = keep.to(dev)
+                src = src.filtered(keep, None, n_kept, reuse=self._filt.pop(("L", year_idx, k), None))
+                self._filt[("L", year_idx, k)] = src
+                csrs.append(src)
+                flags.append(keep)
             if mess_ref and drop[k] > 0:
                 noise = torch.nn.functional.dropout(torch.ones((N, widths[k + 1]), dtype=torch.float32),
                                                     p=drop[k], training=True)
@@ -198,8 +237,58 @@ class NGCF(nn.Module):
             else:
                 masks.append(None)
         # the thinned matrices are not symmetric: their transposes are built only if a backward needs them
-        return (csrs if node_ref else None, (lambda: [self._transposed_csr(i, v) for i, v in kept]) if node_ref else None,
+        return (csrs if node_ref else None, (lambda: self._thinned_transposes(year_idx, csrs, flags)) if node_ref else None,
                 masks if mess_ref else None)
+
+    def _thinned_transposes(self, year_idx: int, csrs, flags):
+        """(thinned L_k)^T for every layer, as device compactions of the cached L^T (and of each other): entry j of the transpose
+        is kept iff the flag of its twin in L_k-1 is set, found through an entry map that is carried from layer to layer."""
+        dev = self._dev()
+        src_t = self.laplacian_csr_t(year_idx)
+        emap = self._csr_cache.get(("Tmap", year_idx, id(self.lap_list[year_idx]), str(dev)))
+        if emap is None:
+            raise RuntimeError("reference-mode node dropout: more than 2^31 stored entries")
+        lib = _eng._lib.load()
+        out = []
+        for k, (csr_k, keep) in enumerate(zip(csrs, flags)):
+            n_src = src_t.nnz
+            t = src_t.filtered(keep, emap, csr_k.nnz, reuse=self._filt.pop(("T", year_idx, k), None))
+            self._filt[("T", year_idx, k)] = t
+            out.append(t)
+            if k + 1 < len(csrs):
+                nxt = self._filt_maps.get((year_idx, k))
+                if nxt is None or nxt.numel() < max(csr_k.nnz, 1) or nxt.device != dev:
+                    nxt = self._filt_maps[(year_idx, k)] = torch.empty(max(n_src, 1), dtype=torch.int32, device=dev)
+                with _eng._on(dev):
+                    _eng._lib.check(lib.ngcf_csr_filter_remap(t._h, _eng._ptr(keep), _eng._ptr(emap), n_src,
+                                                              _eng.C.c_void_p(csr_k.filter_pos), _eng._ptr(nxt), _eng._stream()))
+                emap = nxt[:csr_k.nnz]
+            src_t = t
+        return out
+
+    def _reference_draws_rebuild(self, year_idx: int, drop, mess_ref: bool):
+        """The same draws for a `lap_list` entry whose COO is not row-sorted: the mask numbers entries in stored order, so the
+        thinned COO is formed with torch indexing and a CSR is built from it per layer (one-off shapes; `Matrix` emits sorted rows)."""
+        dev = self._dev()
+        N = self.n_user + self.n_item
+        widths = [self.emb_size] + list(self.weight_size)
+        csrs, kept, masks = [], [], []
+        L = self.lap_list[year_idx]
+        idx = L._indices().to(dev)
+        val = L._values().to(device=dev, dtype=torch.float32)
+        for k in range(self.n_layer):
+            mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
+                                               p=self.node_dropout, training=True).type(torch.bool).to(dev)
+            idx, val = idx[:, mask], val[mask]
+            order = torch.sort(idx[0], stable=True).indices
+            csrs.append(_eng.LaplacianCSR.from_coo(idx[0][order], idx[1][order], val[order], N, N))
+            kept.append((idx, val))
+            if mess_ref and drop[k] > 0:
+                noise = torch.nn.functional.dropout(torch.ones((N, widths[k + 1]), dtype=torch.float32), p=drop[k], training=True)
+                masks.append(noise.to(dev, non_blocking=False))
+            else:
+                masks.append(None)
+        return csrs, (lambda: [self._transposed_csr(i, v)[0] for i, v in kept]), masks if mess_ref else None
 
     def _private_seeds(self, n: int):
         """64-bit seeds for the device-mode hash streams, from a generator of the module's own: the default CPU stream is
@@ -251,6 +340,47 @@ class NGCF(nn.Module):
     # ------------------------------------------------------------------------------------
     # forward (NGCF.py:102-156)
     # ------------------------------------------------------------------------------------
+    def _graph_key(self, dev, sizes, year_idx):
+        ptrs = tuple(p.data_ptr() for p in self.parameters())
+        return (sizes, year_idx, id(self.lap_list[year_idx]), str(dev), ptrs)
+
+    def _forward_graphed(self, dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item):
+        """The inference forward as a hipGraph replay (graphed.GraphedForward): captured on first use per (index vector lengths,
+        year slice), re-captured when a parameter or `lap_list` entry was replaced (`.to()`, a new tensor assigned); in-place
+        updates (`load_state_dict`, optimizer steps) need nothing - the graph reads the parameters when it runs.  Returns fresh
+        tensors like the eager path.  Out-of-range ids raise IndexError at the latest `index_check_every` calls later (the status
+        word is sticky; `check_indices_now()` reads it on demand)."""
+        from .graphed import GraphedForward
+        year_idx = int(year.min().item() % 18) if year.numel() else 0   # == year.unique()[0] % 18, NGCF.py:117
+        sizes = (len(u_id), len(pos_item), len(neg_item))
+        for v in (age, sex, month, day, dow):
+            if len(v) != sizes[0]:
+                raise RuntimeError("shape mismatch: feature index vectors and u_id differ in length")
+        key = self._graph_key(dev, sizes, year_idx)                    # IndexError for a bad year_idx, like the reference
+        g = self._graphs.pop(key, None)
+        if g is None:
+            if key not in self._graph_seen:                            # first call of a shape runs eagerly: its ids are checked at once,
+                if len(self._graph_seen) > 64:                         # and a shape that never comes back is never captured
+                    self._graph_seen.clear()
+                self._graph_seen.add(key)
+                return None
+            stale = [k for k in self._graphs if k[:4] == key[:4]]      # same shape, replaced parameters: those graphs are dead
+            for k in stale + list(self._graphs)[:max(0, len(self._graphs) - len(stale) - 7)]:
+                self._graphs.pop(k, None)
+            g = GraphedForward(self, sizes[0], year_idx, with_neg=sizes[2] > 0, pos_size=sizes[1], neg_size=sizes[2] or None)
+        self._graphs[key] = g
+        self._graph_calls += 1
+        u, p, n = g(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item,
+                    neg_item=neg_item if sizes[2] > 0 else None, node_flag=False, check=False)
+        if self.check_indices and self._graph_calls % max(1, int(self.index_check_every)) == 0:
+            g.check_status()
+        return u.clone(), p.clone(), (n.clone() if sizes[2] > 0 else torch.empty(0))
+
+    def check_indices_now(self):
+        """Raise IndexError if any graph-replayed forward since the last check saw an out-of-range id."""
+        for g in self._graphs.values():
+            g.check_status()
+
     def forward(self, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag):
         dev = self._dev()
         status = self._status_buf(dev)
@@ -259,6 +389,12 @@ class NGCF(nn.Module):
             # the reference fails at NGCF.py:114 with a shape-mismatch RuntimeError for such widths
             raise RuntimeError(f"shape mismatch: value tensor of shape [{len(u_id)}, {5 * fw}] cannot be broadcast "
                                f"to indexing result of shape [{len(u_id)}, {self.emb_size}]")
+        if (self.auto_graph and not self.training and not node_flag and not torch.is_grad_enabled() and len(u_id) > 0 and
+                len(pos_item) > 0 and (self.n_user + self.n_item) * (self.emb_size + sum(self.weight_size)) * 4 <= self.auto_graph_max_bytes
+                and not torch.cuda.is_current_stream_capturing()):
+            out = self._forward_graphed(dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item)
+            if out is not None:
+                return out
         # feature injection into user_embedding.weight.data, no autograd (NGCF.py:103-115)
         with torch.no_grad():
             keep = _eng.feature_inject(

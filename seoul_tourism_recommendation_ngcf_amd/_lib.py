@@ -33,6 +33,9 @@ PROTOTYPES = {
     "ngcf_csr_from_arrays": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, C.POINTER(_vp), _vp]),
     "ngcf_csr_plan": (C.c_int, [_vp, _i32, _vp]),
     "ngcf_csr_set_mode": (C.c_int, [_vp, C.c_int, _vp]),
+    "ngcf_csr_filter": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(_vp), _vp]),
+    "ngcf_csr_filter_pos": (_vp, [_vp]),
+    "ngcf_csr_filter_remap": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ngcf_csr_free": (None, [_vp]),
     "ngcf_csr_nnz": (_i64, [_vp]),
     "ngcf_csr_n_rows": (_i64, [_vp]),
@@ -63,15 +66,13 @@ PROTOTYPES = {
     "ngcf_bpr_workspace_bytes": (_i64, [_i64]),
     "ngcf_bpr_fused_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp]),
     "ngcf_bpr_backward_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "ngcf_scatter_add_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "ngcf_segment_sum_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_layer_bwd_pre_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _f32, _f32, _u64, _vp, _i64,
                                          _vp, _vp, _i64, _vp]),
-    "ngcf_spmm_scatter_rows_f32": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, _vp]),
+    "ngcf_spmm_t_rows_f32": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _i64, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, _vp, _i64, _vp]),
     "ngcf_layer_bwd_input_workspace_bytes": (_i64, [C.c_int]),
     "ngcf_layer_bwd_input_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64,
                                            _vp, _i64, _vp]),
-    "ngcf_sp_concat_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp]),
-    "ngcf_layer_bwd_combine_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_bwd_weight_workspace_bytes": (_i64, []),
     "ngcf_layer_bwd_weight_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _i64, _vp]),
     "ngcf_add_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
@@ -80,6 +81,19 @@ PROTOTYPES = {
     "ngcf_shard_plan": (C.c_int, [C.POINTER(_i64), _i64, _i64, C.c_int, C.POINTER(_i64)]),
     "ngcf_allgather_rows": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp]),
     "ngcf_comm_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "ngcf_p2p_create": (C.c_int, [C.c_int, C.c_int, _i64, C.c_char_p, C.POINTER(_vp)]),
+    "ngcf_p2p_destroy": (None, [_vp]),
+    "ngcf_p2p_handle": (C.c_int, [_vp, _vp]),
+    "ngcf_p2p_connect": (C.c_int, [_vp, _vp]),
+    "ngcf_p2p_local": (_vp, [_vp]),
+    "ngcf_p2p_bytes": (_i64, [_vp]),
+    "ngcf_p2p_publish": (C.c_int, [_vp, C.c_int, _u64, _vp]),
+    "ngcf_p2p_pull": (C.c_int, [_vp, C.c_int, C.c_int, _u64, _i64, _vp, _i64, C.c_double]),
+    "ngcf_p2p_ack": (C.c_int, [_vp, C.c_int, C.c_int, _u64]),
+    "ngcf_p2p_wait_acks": (C.c_int, [_vp, C.c_int, _u64, C.c_double]),
+    "ngcf_p2p_fence": (C.c_int, [_vp, _vp]),
+    "ngcf_p2p_join": (C.c_int, [_vp, _vp]),
+    "ngcf_sum_slots_f32": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp]),
 }
 
 _lib = None

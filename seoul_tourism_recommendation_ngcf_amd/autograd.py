@@ -3,8 +3,8 @@
 `propagate_forward` issues the HIP layer kernels for NGCF.py:120-147 (inference path, nothing saved).
 `Propagate` / `GatherTriple` / `BPRLoss` are `torch.autograd.Function`s so that `loss.backward()`
 (experiment.py:57) reaches every parameter: their backward runs the HIP kernels of the "backward pass" section
-of include/ngcf_hip.h plus two plain library GEMMs per layer (`dM @ [W1|W2]`, `dM^T @ [S|P]`) and `L^T . dLE`
-on the SpMM kernel.
+of include/ngcf_hip.h - weight and input gradients on the fp32 matrix cores, `L^T . dLE` on the SpMM kernels; no library
+GEMM at any width.
 """
 from __future__ import annotations
 
@@ -20,6 +20,12 @@ from .engine import _ptr, _row_major_ld, _stream
 
 SPARSE_LAST_LAYER = True        # row-sparse backward of the last layer (Propagate.backward); False: always the dense path
 sparse_last_layer_calls = 0     # how often the row-sparse path ran (tests)
+
+
+def _padded_rows(n: int, d: int, dev) -> torch.Tensor:
+    """[n, d] fp32 whose rows start on 128-byte lines (leading dimension rounded up to 32 floats): the float4 / L2-swept SpMM and
+    the branch-free dense path then apply at the reference's own widths too (65 -> 96)."""
+    return torch.empty((n, (d + 31) // 32 * 32), dtype=torch.float32, device=dev)[:, :d]
 
 
 def _write_e0(owner, user_w, item_w, all_E, U, d0):
@@ -70,7 +76,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
         if k < n_layer - 1:
             buf = owner._carry[k % 2]
             if buf is None or buf.device != dev or tuple(buf.shape) != (N, d_out):
-                buf = torch.empty((N, d_out), dtype=torch.float32, device=dev)
+                buf = _padded_rows(N, d_out, dev)
                 owner._carry[k % 2] = buf
             carry = buf
         mk = None if masks is None else masks[k]
@@ -92,24 +98,17 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
 def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None, row_ids=None):
     lib = _lib.load()
     n_rows, d = Cc.shape
-    dM = torch.empty((n_rows, d), dtype=torch.float32, device=Cc.device)
+    # rows padded to a multiple of 32 floats: 128-byte aligned rows at the reference's own widths too (65 -> 96), which is what
+    # the fused input-gradient kernel reads dM through (16-byte pieces; columns past d are masked there)
+    ldm = (d + 31) // 32 * 32
+    dM = torch.empty((n_rows, ldm), dtype=torch.float32, device=Cc.device)[:, :d]
     with _eng._on(Cc.device):
         _lib.check(lib.ngcf_layer_bwd_pre_f32(_ptr(dN), 0 if dN is None else _row_major_ld(dN, "dN"), _ptr(dC),
                                               0 if dC is None else _row_major_ld(dC, "dC"), _ptr(Cc),
                                               _row_major_ld(Cc, "C"), n_rows, d, leaky, float(drop_p), int(seed),
                                               _ptr(mask), 0 if mask is None else _row_major_ld(mask, "drop_mask"),
-                                              _ptr(row_ids), _ptr(dM), d, _stream()))
+                                              _ptr(row_ids), _ptr(dM), ldm, _stream()))
     return dM
-
-
-def _sp_concat(LE, E):
-    lib = _lib.load()
-    n_rows, d = LE.shape
-    SP = torch.empty((n_rows, 2 * d), dtype=torch.float32, device=LE.device)
-    with _eng._on(LE.device):
-        _lib.check(lib.ngcf_sp_concat_f32(_ptr(LE), _row_major_ld(LE, "LE"), _ptr(E), _row_major_ld(E, "E"), n_rows, d,
-                                          _ptr(SP), _stream()))
-    return SP
 
 
 def _bwd_weight(dM, LE, E, ws):
@@ -138,18 +137,6 @@ def _bwd_weight(dM, LE, E, ws):
                     gW[o0:o1, c0:c1] = blk[:, :c1 - c0]
                     gW[o0:o1, d_in + c0:d_in + c1] = blk[:, c1 - c0:]
     return gW, gb
-
-
-def _bwd_combine(dSP, LE, E):
-    lib = _lib.load()
-    n_rows, d = LE.shape
-    d4 = (d + 31) // 32 * 32   # 128-byte aligned rows: L^T . dLE then runs on the float4 / swept kernels at any width
-    dLE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
-    dE = torch.empty((n_rows, d4), dtype=torch.float32, device=LE.device)[:, :d]
-    with _eng._on(LE.device):
-        _lib.check(lib.ngcf_layer_bwd_combine_f32(_ptr(dSP), _ptr(LE), _row_major_ld(LE, "LE"), _ptr(E),
-                                                  _row_major_ld(E, "E"), n_rows, d, _ptr(dLE), d4, _ptr(dE), d4, _stream()))
-    return dLE, dE
 
 
 def _bwd_input(dM, w1, w2, LE, E, ws):
@@ -195,7 +182,7 @@ class Propagate(torch.autograd.Function):
             d_out = widths[k + 1]
             ed = None if edge_drops is None else (edge_drops[k][0], edge_drops[k][1], False)
             LE = _eng.spmm(csrs[k], prev, ws=owner._ws, edge_drop=ed)        # saved for the backward
-            carry = torch.empty((N, d_out), dtype=torch.float32, device=dev)
+            carry = _padded_rows(N, d_out, dev)
             _eng.layer_dense(LE, prev, w1[k].detach(), b1[k].detach(), w2[k].detach(), b2[k].detach(), carry,
                              all_E[:, off:off + d_out], owner._ws, drop[k], seeds[k], None if masks is None else masks[k])
             ins.append(prev)
@@ -224,15 +211,14 @@ class Propagate(torch.autograd.Function):
         # The gradient that reaches all_E from the row gathers is non-zero on at most 3 B rows, and GatherTriple hands it over as a
         # row-sparse tensor (rows + a compact [R, D] block of values; autograd densifies it only if another consumer of all_E
         # adds a dense gradient).  The LAST layer's backward then involves those rows only: normalise/LeakyReLU backward, both
-        # weight gradients and the input gradients on a compacted [R, d] problem, and L^T . dLE as a scatter over the stored
-        # entries of those R rows of L (ngcf_spmm_scatter_rows_f32: ~1 M entries instead of 100 M on C3) - instead of a full
-        # SpMM and four passes over 1.1 M rows.  Earlier layers are dense (their dC is), but the part of their incoming
+        # weight gradients and the input gradients on a compacted [R, d] problem, and L^T . dLE as one pass over the stored entries
+        # of L^T that picks the R non-zero rows of dLE through a slot table (ngcf_spmm_t_rows_f32: fixed summation order) -
+        # instead of a full SpMM and four passes over 1.1 M rows.  Earlier layers are dense (their dC is), but the part of their incoming
         # gradient that comes through the normalised all_E block is still confined to the R rows: the dense pass runs with
         # dN = 0 and the R rows are redone with their dN.
         rows = gv = None
         if g_all.is_sparse:
-            # (the row scatter keeps a row of X in 8 registers per lane: the last layer's input width must be <= 512)
-            if SPARSE_LAST_LAYER and widths[n - 1] <= 512:
+            if SPARSE_LAST_LAYER:
                 g = g_all.coalesce()
                 rows, gv = g.indices()[0].contiguous(), g.values().contiguous()
             else:
@@ -253,15 +239,13 @@ class Propagate(torch.autograd.Function):
                 gW, gb = _bwd_weight(dM, LE_c, E_c, ws)
                 gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
                 gb1[k], gb2[k] = 2.0 * gb, gb
-                if d_out % 4 == 0 and d_out >= 4:
-                    dLE_c, dE_c = _bwd_input(dM, w1[k], w2[k], LE_c, E_c, ws)
-                else:
-                    dLE_c, dE_c = _bwd_combine(dM.mm(torch.cat((w1[k], w2[k]), dim=1)), LE_c, E_c)
-                d4 = (d_in + 31) // 32 * 32
-                dE = torch.zeros((all_E.shape[0], d4), dtype=torch.float32, device=all_E.device)[:, :d_in]
-                dE[rows] = dE_c
+                dLE_c, dE_c = _bwd_input(dM, w1[k], w2[k], LE_c, E_c, ws)
+                N = int(all_E.shape[0])
+                dE = _padded_rows(N, d_in, all_E.device)
+                slot = torch.full((N,), -1, dtype=torch.int32, device=all_E.device)
+                slot[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=all_E.device)
                 ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1])
-                _eng.spmm_scatter_rows(ctx.csrs[k], rows, dLE_c, dE, ed)         # dE += (thinned L)^T . dLE
+                _eng.spmm_t_rows(ctx.csrs_t[k], slot, dLE_c, dE_c, dE, ws, ed)     # dE = dE_direct + (thinned L)^T . dLE, fixed order
                 dC = dE
                 continue
             if rows is not None:
@@ -273,12 +257,7 @@ class Propagate(torch.autograd.Function):
             gW, gb = _bwd_weight(dM, LE_k, E_k, ws)                              # MFMA kernel, operand formed on the fly; bias too
             gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
             gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
-            if d_out % 4 == 0 and d_out >= 4:                                    # dM rows are contiguous [N, d_out]: 16-byte aligned
-                dLE, dE = _bwd_input(dM, w1[k], w2[k], LE_k, E_k, ws)             # one MFMA kernel, dS/dP never stored
-            else:
-                dSP = dM.mm(torch.cat((w1[k], w2[k]), dim=1))                    # odd widths: library GEMM [N, 2 d_in] + combine
-                dLE, dE = _bwd_combine(dSP, LE_k, E_k)
-                del dSP
+            dLE, dE = _bwd_input(dM, w1[k], w2[k], LE_k, E_k, ws)                 # one MFMA kernel at any width, dS/dP never stored
             del dM
             ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], True)
             _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed))     # dE += (thinned L)^T . dLE
@@ -317,15 +296,17 @@ class GatherTriple(torch.autograd.Function):
         # the sorted unique rows (one host sync for their count) and a compact [R, D] block the duplicates are added into -
         # instead of a zero-filled [N, D] matrix (2.3 GB at C3).  Propagate.backward works on those rows; any other consumer of
         # all_E gets the dense sum from autograd.
-        rows, inv = torch.unique(torch.cat([r for _, r in live]), return_inverse=True)
+        # Duplicates (the same user or item several times in a batch) are added in batch order, row by row, by one kernel with a
+        # fixed summation order (ngcf_segment_sum_rows_f32; r02 used float atomics and the gradients differed from run to run).
+        rows, inv, counts = torch.unique(torch.cat([r for _, r in live]), return_inverse=True, return_counts=True)
         R = int(rows.numel())
-        vals = torch.zeros((R, D), dtype=torch.float32, device=dev)
+        g_all = live[0][0] if len(live) == 1 else torch.cat([g for g, _ in live], dim=0)
+        order = torch.sort(inv, stable=True).indices
+        segptr = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=segptr[1:])
+        vals = torch.empty((R, D), dtype=torch.float32, device=dev)
         with _eng._on(dev):
-            at = 0
-            for g, r in live:
-                ix = inv[at:at + r.numel()].contiguous()
-                at += r.numel()
-                _lib.check(lib.ngcf_scatter_add_rows_f32(_ptr(vals), D, D, _ptr(ix), ix.numel(), 0, R, _ptr(g), D, _stream()))
+            _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), R, _ptr(vals), D, _stream()))
         G = torch.sparse_coo_tensor(rows[None], vals, (N, D), is_coalesced=True)
         return (G, None, None, None, None, None)
 

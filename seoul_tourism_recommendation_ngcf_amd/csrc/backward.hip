@@ -1,11 +1,11 @@
 // backward.hip - kernels of the backward pass.
-#include "common.h"
+#include "spmm_device.h"
 
 // =============================================================================================
 // Backward pass (`loss.backward()` in experiment.py:57).
-// The two plain GEMMs per layer (dM.[W1|W2] and dM^T.[S|P]) are library GEMMs issued by the host; everything
-// around them is fused here: BPR gradient, gather scatter-add, normalise/dropout/LeakyReLU backward,
-// the [LE+E | LE*E] operand, and the combination of the GEMM result into dLE and the direct part of dE.
+// Everything the backward runs besides L^T . dLE on the SpMM kernels: BPR gradient, the gathers' gradient rows summed per
+// distinct row, normalise/dropout/LeakyReLU backward, weight and input gradients on the fp32 matrix cores, and L^T . dLE for
+// a row-sparse dLE.  No library GEMM, no atomics: every sum has a fixed order (bit-identical gradients from run to run).
 // =============================================================================================
 
 // ---- BPR backward (bprloss.py:15-22) ----------------------------------------------------------
@@ -65,26 +65,42 @@ extern "C" int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p,
     return NGCF_OK;
 }
 
-// ---- gather backward: G[row_off + idx[b], :] += g[b, :] (duplicates add up) -------------------
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float *__restrict__ G, int64_t ld, int d,
-                                                               const int64_t *__restrict__ idx, int64_t B, int64_t row_off,
-                                                               int64_t n_idx_rows, const float *__restrict__ g, int64_t ldg)
+// ---- gather backward: the gradient rows of the (users, positive items, negative items) gathers (NGCF.py:151-155), summed per
+// distinct row of all_E in a FIXED order: out[r, :] = sum over j in [segptr[r], segptr[r+1]) of g[order[j], :], in that order
+// (the caller sorts the gathered positions by row, stable, so duplicates add up in batch order).  No atomics: two runs give
+// the same bits.  One wave per output row.
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ g, int64_t ldg, int d,
+                                                               const int64_t *__restrict__ order, const int64_t *__restrict__ segptr,
+                                                               int64_t n_seg, float *__restrict__ out, int64_t ldo)
 {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int64_t i = idx[b];
-    if (i < 0 || i >= n_idx_rows) return;
-    float *dst = G + (row_off + i) * ld;
-    for (int j = threadIdx.x & 63; j < d; j += 64) atomicAdd(&dst[j], g[b * ldg + j]);
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_seg) return;
+    const int64_t j0 = segptr[r], j1 = segptr[r + 1];
+    // four chains over the segment (positions j0 + 4 i + q), combined as (s0 + s1) + (s2 + s3): a fixed order whose loads do not
+    // wait for each other (a popular item is gathered 20 times in a batch of 1 024 on the Seoul graph's 100 items)
+    for (int c = threadIdx.x & 63; c < d; c += 64) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            const int64_t o0 = order[j], o1 = order[j + 1], o2 = order[j + 2], o3 = order[j + 3];
+            s0 += g[o0 * ldg + c];
+            s1 += g[o1 * ldg + c];
+            s2 += g[o2 * ldg + c];
+            s3 += g[o3 * ldg + c];
+        }
+        for (; j < j1; ++j) s0 += g[order[j] * ldg + c];
+        out[r * ldo + c] = (s0 + s1) + (s2 + s3);
+    }
 }
 
-extern "C" int ngcf_scatter_add_rows_f32(float *G, int64_t ld, int d, const int64_t *idx, int64_t B, int64_t row_off,
-                                         int64_t n_idx_rows, const float *g, int64_t ldg, void *stream_)
+extern "C" int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr,
+                                         int64_t n_seg, float *out, int64_t ldo, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (B == 0) return NGCF_OK;
-    if (!G || !idx || !g || d <= 0 || ld < d || ldg < d) return fail(NGCF_ERR_ARG, "scatter_add_rows: bad argument");
-    scatter_add_rows_kernel<<<dim3((unsigned)((B + 3) / 4)), 256, 0, stream>>>(G, ld, d, idx, B, row_off, n_idx_rows, g, ldg);
+    if (n_seg == 0) return NGCF_OK;
+    if (!g || !order || !segptr || !out || d <= 0 || ldg < d || ldo < d || n_seg < 0) return fail(NGCF_ERR_ARG, "segment_sum_rows: bad argument");
+    if ((n_seg + 3) / 4 >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "segment_sum_rows: too many rows");
+    segment_sum_rows_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), 256, 0, stream>>>(g, ldg, d, order, segptr, n_seg, out, ldo);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -146,56 +162,6 @@ extern "C" int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float 
     return NGCF_OK;
 }
 
-// ---- SP = [LE + E | LE * E]  (the GEMM operand of the forward, needed for dW1/dW2) ------------
-__global__ void sp_concat_kernel(const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ E, int64_t ldE,
-                                 int64_t n_rows, int d, float *__restrict__ SP)
-{
-    const int64_t total = n_rows * d;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / d;
-        const int j = (int)(i % d);
-        const float a = LE[r * ldLE + j], b = E[r * ldE + j];
-        SP[r * 2 * d + j] = a + b;
-        SP[r * 2 * d + d + j] = a * b;
-    }
-}
-
-extern "C" int ngcf_sp_concat_f32(const float *LE, int64_t ldLE, const float *E, int64_t ldE, int64_t n_rows, int d, float *SP,
-                                  void *stream_)
-{
-    if (n_rows == 0) return NGCF_OK;
-    if (!LE || !E || !SP || d <= 0) return fail(NGCF_ERR_ARG, "sp_concat: bad argument");
-    sp_concat_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(LE, ldLE, E, ldE, n_rows, d, SP);
-    LAUNCH_CHECK();
-    return NGCF_OK;
-}
-
-// ---- dSP = dM.[W1 | W2] -> dLE = dS + dP*E ; dE_direct = dS + dP*LE ----------------------------
-__global__ void layer_bwd_combine_kernel(const float *__restrict__ dSP, const float *__restrict__ LE, int64_t ldLE,
-                                         const float *__restrict__ E, int64_t ldE, int64_t n_rows, int d,
-                                         float *__restrict__ dLE, int64_t ldd, float *__restrict__ dE, int64_t lde)
-{
-    const int64_t total = n_rows * d;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / d;
-        const int j = (int)(i % d);
-        const float ds = dSP[r * 2 * d + j], dp = dSP[r * 2 * d + d + j];
-        dLE[r * ldd + j] = fmaf(dp, E[r * ldE + j], ds);
-        dE[r * lde + j] = fmaf(dp, LE[r * ldLE + j], ds);
-    }
-}
-
-extern "C" int ngcf_layer_bwd_combine_f32(const float *dSP, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
-                                          int64_t n_rows, int d, float *dLE, int64_t ldd, float *dE, int64_t lde,
-                                          void *stream_)
-{
-    if (n_rows == 0) return NGCF_OK;
-    if (!dSP || !LE || !E || !dLE || !dE || d <= 0 || ldd < d || lde < d) return fail(NGCF_ERR_ARG, "layer_bwd_combine: bad argument");
-    layer_bwd_combine_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(dSP, LE, ldLE, E, ldE, n_rows, d, dLE, ldd,
-                                                                                          dE, lde);
-    LAUNCH_CHECK();
-    return NGCF_OK;
-}
 
 // out[r, :] += add[r, :]   (dE = dE_direct + L^T.dLE accumulation)
 __global__ void add_rows_kernel(float *__restrict__ out, int64_t ldo, const float *__restrict__ add, int64_t lda, int64_t n_rows, int d)
@@ -345,9 +311,19 @@ __global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, cons
     }
     const int o = i / (2 * d_in), c = i % (2 * d_in);
     const int src = c < d_in ? c : P + (c - d_in);
-    float s = 0.f;
-    for (int w = 0; w < n_wg; ++w) s += partial[((int64_t)w * kBwM + o) * kBwN + src];
-    gW[i] = s;
+    // four independent chains (workgroups w = q mod 4), combined in a fixed order: the loads of a chain do not wait for each other
+    const float *p = partial + (int64_t)o * kBwN + src;
+    const int64_t step = (int64_t)kBwM * kBwN;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= n_wg; w += 4) {
+        s0 += p[(w + 0) * step];
+        s1 += p[(w + 1) * step];
+        s2 += p[(w + 2) * step];
+        s3 += p[(w + 3) * step];
+    }
+    for (; w < n_wg; ++w) s0 += p[w * step];
+    gW[i] = (s0 + s1) + (s2 + s3);
 }
 
 extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void)
@@ -371,13 +347,18 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
     float *partial_bias = partial + (int64_t)kBwWGs * kBwM * kBwN;
     const int P = (int)align_up(d_in, 32);
     const bool al = ldM % 4 == 0 && ldLE % 4 == 0 && ldE % 4 == 0 && aligned16(dM) && aligned16(LE) && aligned16(E);
+    // workgroups: one per CU on a large matrix; on a small one (the Seoul graph's 5 940 rows are 186 blocks, a compacted last
+    // layer a few dozen) every workgroup should still see >= 4 blocks - each writes a 128 KB partial that the reduction reads
+    // back (256 of them: 33 MB and 116 us for a 65 x 130 gradient)
+    const int64_t n_blocks = (n_rows + kBwRows - 1) / kBwRows;
+    const int n_wg = (int)std::min<int64_t>(kBwWGs, std::max<int64_t>(1, (n_blocks + 3) / 4));
     if (al)
-        bwd_weight_kernel<true><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
+        bwd_weight_kernel<true><<<n_wg, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     else
-        bwd_weight_kernel<false><<<kBwWGs, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
+        bwd_weight_kernel<false><<<n_wg, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     LAUNCH_CHECK();
     const int total = d_out * 2 * d_in + (gb ? d_out : 0);
-    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, partial_bias, kBwWGs, d_in, d_out, P, gW, gb);
+    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, partial_bias, n_wg, d_in, d_out, P, gW, gb);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -521,7 +502,7 @@ extern "C" int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows == 0) return NGCF_OK;
-    if (!dM || !W1 || !W2 || !LE || !E || !dLE || !dE || d_in <= 0 || d_out < 4 || ldM < d_out || ldLE < d_in || ldE < d_in ||
+    if (!dM || !W1 || !W2 || !LE || !E || !dLE || !dE || d_in <= 0 || d_out < 1 || ldM < d_out || ldLE < d_in || ldE < d_in ||
         ldd < d_in || lde < d_in)
         return fail(NGCF_ERR_ARG, "layer_bwd_input: bad argument");
     if (ldM % 4 != 0 || !aligned16(dM) || ldM < align_up(d_out, 4))
@@ -552,66 +533,119 @@ extern "C" int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_
 
 
 // =============================================================================================
-// L^T . X for a ROW-SPARSE X (r02).  The gradient that reaches the last layer comes from the three row gathers only
-// (NGCF.py:151-155): dLE of that layer is non-zero on at most 3 B rows, so out = L^T . dLE needs only the stored entries
-// of those rows of L (column r of L^T is row r of L): out[c, :] += v * X[i, :] for every entry (rows[i], c, v).
-// ~1 M entries instead of 100 M on C3 at B = 1024.  One workgroup per (row, 2048-entry segment); a wave takes 64 entries at
-// a time and adds 256-byte pieces with float atomics (memory-side, ~1.3 TB/s chip-wide): the order of the additions into
-// one output element is not fixed, like the index_put_ / scatter_add gradients of the reference on a GPU.
+// L^T . X for a ROW-SPARSE X.  The gradient that reaches the last layer comes from the three row gathers only
+// (NGCF.py:151-155): dLE of that layer is non-zero on R <= 3 B rows, given compacted as X [R, d] with a table slot[N]
+// (slot[r] = row of X that holds matrix row r, -1 = zero row).  out = init + L^T . dLE is formed on the CSR of L^T, row by
+// row: a wave walks the stored entries (c, r, v) of output row c 64 at a time, looks slot[r] up (4 bytes per entry out of a
+// table that lives in L2), compacts the hits with a ballot and adds v * X[slot[r], :] for each hit in entry order - so every
+// output element is a sum in a FIXED order (r03: this replaces a scatter with float atomics, whose gradients differed from run
+// to run).  Rows cut by the CSR's segment plan go through partial sums + spmm_fixup_kernel like every other product.  The whole
+// of `out` is written: rows without a hit get init or zero, so no zero-fill and no index_put precede it.
+// Cost: one pass over colidx (400 MB on C3, ~0.15 ms) + R-proportional work, instead of a full L^T . dLE SpMM (1.5 ms).
 // =============================================================================================
-static constexpr int kScatSeg = 2048;
-
-__global__ __launch_bounds__(256) void spmm_scatter_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
-                                                                const float *__restrict__ vals, const int64_t *__restrict__ rows,
-                                                                int64_t n_sel, int64_t n_rows, const float *__restrict__ X, int64_t ldx,
-                                                                int d, float *__restrict__ out, int64_t ldo, EdgeDrop dr)
+template <int NQ>      // this lane's columns lane, lane + 64, ..: d <= 64 * NQ
+__global__ __launch_bounds__(256) void spmm_t_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                          const float *__restrict__ vals, int64_t n_rows,
+                                                          const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
+                                                          int64_t n_seg, int64_t seg_blocks, int seg_len,
+                                                          const int32_t *__restrict__ slot, const float *__restrict__ X, int64_t ldx, int d,
+                                                          const float *__restrict__ init, int64_t ldi, float *__restrict__ out, int64_t ldo,
+                                                          float *__restrict__ partial, int dp, EdgeDrop dr)
 {
-    const int64_t i = blockIdx.x;
-    if (i >= n_sel) return;
-    const int64_t row = rows[i];
-    if (row < 0 || row >= n_rows) return;
-    const int64_t b0 = rowptr[row] + (int64_t)blockIdx.y * kScatSeg;
-    const int64_t b1 = min(rowptr[row + 1], b0 + kScatSeg);
-    if (b0 >= b1) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float x[8];                                            // this lane's columns lane, lane+64, ... of X[i, :]  (d <= 512)
+    int64_t begin, end, row;
+    float *dst;
+    bool first;                 // this unit starts its row: it carries the row's init term
+    if ((int64_t)blockIdx.x < seg_blocks) {
+        const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+        if (s >= n_seg) return;
+        begin = seg_begin[s];
+        row = seg_row[s];
+        const int64_t row_end = rowptr[row + 1];
+        end = begin + seg_len < row_end ? begin + seg_len : row_end;
+        first = begin == rowptr[row];
+        dst = partial + s * (int64_t)dp;
+    } else {
+        row = ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
+        if (row >= n_rows) return;
+        begin = rowptr[row];
+        end = rowptr[row + 1];
+        if (end - begin > seg_len) return;   // cut row: produced from its segments
+        first = true;
+        dst = out + row * ldo;
+    }
+    float acc[NQ];
+    const int s_self = first && init ? slot[row] : -1;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) x[q] = lane + 64 * q < d ? X[i * ldx + lane + 64 * q] : 0.f;
-    for (int64_t base = b0 + wave * 64; base < b1; base += 256) {
-        const int cnt = (int)min<int64_t>(64, b1 - base);
-        int c = 0;
+    for (int q = 0; q < NQ; ++q) acc[q] = (s_self >= 0 && lane + 64 * q < d) ? init[(int64_t)s_self * ldi + lane + 64 * q] : 0.f;
+    for (int64_t base = begin; base < end; base += 64) {
+        const int cnt = (int)(end - base < 64 ? end - base : 64);
+        int sl = -1;
         float v = 0.f;
         if (lane < cnt) {
-            c = colidx[base + lane];
-            v = vals[base + lane];
-            if (dr.n > 0) v = edge_keep(dr, row, c) ? v : 0.f;   // device-side node dropout: the same keep test as the forward SpMM
+            const int c = colidx[base + lane];
+            sl = slot[c];
+            if (sl >= 0) {
+                v = vals[base + lane];
+                if (dr.n > 0 && !edge_keep(dr, row, c)) sl = -1;
+            }
         }
-        for (int j = 0; j < cnt; ++j) {
-            const int cj = __shfl(c, j);
+        unsigned long long hits = __ballot(sl >= 0);
+        while (hits) {                                         // wave-uniform: hits in entry order
+            const int j = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const int sj = __shfl(sl, j);
             const float vj = __shfl(v, j);
-            if (vj == 0.f) continue;                          // dropped entry (wave-uniform)
-            float *o = out + (int64_t)cj * ldo;
+            const float *x = X + (int64_t)sj * ldx;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (lane + 64 * q < d) atomicAdd(o + lane + 64 * q, vj * x[q]);
+            for (int q = 0; q < NQ; ++q)
+                if (lane + 64 * q < d) acc[q] = fmaf(vj, x[lane + 64 * q], acc[q]);
         }
     }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < d) dst[lane + 64 * q] = acc[q];
 }
 
-extern "C" int ngcf_spmm_scatter_rows_f32(const ngcf_csr_t *c, const int64_t *rows, int64_t n_sel, int64_t max_row_len, const float *X,
-                                          int64_t ldx, int d, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
-                                          void *stream_)
+extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, const float *X, int64_t ldx, int d, const float *init,
+                                    int64_t ldi, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
+                                    void *workspace, int64_t workspace_bytes, void *stream_)
 {
-    if (!c) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: null csr");
-    if (n_sel == 0 || max_row_len <= 0) return NGCF_OK;
-    if (!rows || !X || !out || d <= 0 || d > 512 || ldx < d || ldo < d) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: bad argument (d <= 512)");
-    if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: 0..4 seeds expected");
-    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, 0};
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c) return fail(NGCF_ERR_ARG, "spmm_t_rows: null csr");
+    if (c->n_rows == 0) return NGCF_OK;
+    if (!slot || !X || !out || d <= 0 || ldx < d || ldo < d || (init && ldi < d)) return fail(NGCF_ERR_ARG, "spmm_t_rows: bad argument");
+    if (n_seeds < 0 || n_seeds > 4 || (n_seeds > 0 && !seeds)) return fail(NGCF_ERR_ARG, "spmm_t_rows: 0..4 seeds expected");
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "spmm_t_rows: drop_p=%f not in [0,1)", drop_p);
+    EdgeDrop dr{drop_p > 0.f ? n_seeds : 0, (uint32_t)((double)drop_p * 4294967296.0), {0, 0, 0, 0}, 1};   // the CSR walked is L^T
     for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
-    const int64_t segs = (max_row_len + kScatSeg - 1) / kScatSeg;
-    if (n_sel >= (int64_t)1 << 31 || segs > 65535) return fail(NGCF_ERR_ARG, "spmm_scatter_rows: too many rows / too long a row");
-    spmm_scatter_rows_kernel<<<dim3((unsigned)n_sel, (unsigned)segs), 256, 0, (hipStream_t)stream_>>>(
-        c->rowptr, c->colidx, c->vals, rows, n_sel, c->n_rows, X, ldx, d, out, ldo, dr);
-    LAUNCH_CHECK();
+    const int64_t seg_blocks = (c->n_seg + 3) / 4, row_blocks = (c->n_rows + 3) / 4;
+    if (seg_blocks + row_blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm_t_rows: too many rows for one launch");
+    for (int col0 = 0; col0 < d; col0 += 512) {                 // panels of 512 columns (a lane holds 8)
+        const int w = std::min(512, d - col0);
+        const int dp = (int)align_up(w, 4);
+        float *partial = nullptr;
+        if (c->n_seg > 0) {
+            const int64_t need = align_up(c->n_seg * dp * (int64_t)sizeof(float), 256) + 256;
+            if (!workspace || workspace_bytes < need)
+                return fail(NGCF_ERR_WORKSPACE, "spmm_t_rows: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+            partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+        }
+#define NGCF_TROWS(NQ)                                                                                                                \
+    spmm_t_rows_kernel<NQ><<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(                                            \
+        c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, slot, X + col0, ldx, w, \
+        init ? init + col0 : nullptr, ldi, out + col0, ldo, partial, dp, dr)
+        if (w <= 64) NGCF_TROWS(1);
+        else if (w <= 128) NGCF_TROWS(2);
+        else if (w <= 256) NGCF_TROWS(4);
+        else NGCF_TROWS(8);
+#undef NGCF_TROWS
+        LAUNCH_CHECK();
+        if (c->n_heavy > 0) {
+            spmm_fixup_kernel<1><<<dim3((unsigned)((c->n_heavy + 3) / 4)), 256, 0, stream>>>(c->heavy_row, c->heavy_seg_ptr, c->n_heavy, partial,
+                                                                                          dp, w, out + col0, ldo);
+            LAUNCH_CHECK();
+        }
+    }
     return NGCF_OK;
 }

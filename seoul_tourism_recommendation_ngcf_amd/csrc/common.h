@@ -65,6 +65,7 @@ struct NgcfOptions {
     // dense.hip
     int dense_direct = 1;          // NGCF_DENSE_DIRECT: 0 never, 1 up to 8 192 rows, 2 at any row count
     int dense_resident = 1;        // NGCF_DENSE_RESIDENT: 0 keeps the staged kernel
+    int dense_small_tiles = 1;     // NGCF_DENSE_SMALL_TILES: 32-row tiles for <= 128 output columns on <= 16 384 rows
     // csr.hip
     int slice_max_mb = 48;         // NGCF_SLICE_MAX_MB: largest table slice a d-sliced group may gather from
     // spmm_swept.hip (plan)
@@ -122,6 +123,14 @@ struct ngcf_csr {
     int32_t *colidx = nullptr;   // device [nnz]
     float *vals = nullptr;       // device [nnz]
     bool owns = false;
+    // a thinned copy made by ngcf_csr_filter (csr.hip): capacity of colidx / vals, the exclusive scan of the keep flags over the
+    // source's entries (pos[e] = kept entries before e, pos[src nnz] = kept in all), scan scratch; seg_row / heavy_row /
+    // heavy_seg_ptr are then BORROWED from the source (same segment structure, own seg_begin) and nnz may be an upper bound
+    int64_t cap = 0, pos_len = 0;
+    int32_t *pos = nullptr;
+    int32_t *scan_blk = nullptr;
+    bool borrows_plan = false;
+    const struct ngcf_csr *filter_src = nullptr;
     // row segmentation: rows with > seg_len entries are cut into segments
     int32_t seg_len = 0;
     int64_t n_seg = 0, n_heavy = 0;

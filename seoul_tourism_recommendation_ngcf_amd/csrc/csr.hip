@@ -37,6 +37,7 @@ const OptField kOptFields[] = {
     {"tail_overlap", &NgcfOptions::tail_overlap, nullptr},
     {"dense_direct", &NgcfOptions::dense_direct, nullptr},
     {"dense_resident", &NgcfOptions::dense_resident, nullptr},
+    {"dense_small_tiles", &NgcfOptions::dense_small_tiles, nullptr},
     {"slice_max_mb", &NgcfOptions::slice_max_mb, nullptr},
     {"swept_waves", &NgcfOptions::swept_waves, nullptr},
     {"swept_cut", &NgcfOptions::swept_cut, nullptr},
@@ -111,6 +112,12 @@ extern "C" int ngcf_set_option_str(const char *name, const char *value)
 
 static void free_plan(ngcf_csr *c)
 {
+    if (c->borrows_plan) {             // a filtered copy shares its source's segment lists (it owns seg_begin only)
+        c->seg_row = nullptr;
+        c->heavy_row = nullptr;
+        c->heavy_seg_ptr = nullptr;
+        c->borrows_plan = false;
+    }
     if (c->seg_row) (void)hipFree(c->seg_row);
     if (c->seg_begin) (void)hipFree(c->seg_begin);
     if (c->heavy_row) (void)hipFree(c->heavy_row);
@@ -132,6 +139,8 @@ extern "C" void ngcf_csr_free(ngcf_csr_t *c)
         if (c->colidx) (void)hipFree(c->colidx);
         if (c->vals) (void)hipFree(c->vals);
     }
+    if (c->pos) (void)hipFree(c->pos);
+    if (c->scan_blk) (void)hipFree(c->scan_blk);
     delete c;
 }
 
@@ -468,3 +477,229 @@ extern "C" int ngcf_csr_from_coo(const int64_t *rows, const int64_t *cols, const
     return NGCF_OK;
 }
 
+
+
+// =============================================================================================
+// ngcf_csr_filter - thinned copy of a CSR on the device (reference-mode node dropout, NGCF.py:93-100,124-126)
+//
+// The reference rebuilds a COO tensor from `indices[:, mask]` per layer and step.  Entries stay row-sorted under a mask, so
+// the thinned CSR is a stream compaction: an exclusive scan of the keep flags over the source's entries gives every kept
+// entry its new position and every row its new start (rowptr'[r] = pos[rowptr[r]]).  Three passes over the entries
+// (count per 2048-entry block, scan of the block counts in one workgroup, scan inside the blocks + scatter), no host round
+// trip, no allocation after the first call: the destination object is re-used step after step.
+// The segment structure is the source's: a row cut into k segments there keeps k segments here (seg_begin' = rowptr'[row]
+// + j*seg_len; trailing ones may be empty), so seg_row / heavy_row / heavy_seg_ptr are shared and no plan is built.  A row
+// that fell to <= seg_len entries is then produced twice - as a row by the row kernels and from its segments by the fix-up,
+// which runs last and writes the same sum.
+// =============================================================================================
+constexpr int kScanBlock = 2048;        // entries per workgroup (256 threads x 8)
+
+__device__ inline int filter_keep(const uint8_t *__restrict__ keep, const int32_t *__restrict__ map, int64_t e)
+{
+    return keep[map ? (int64_t)map[e] : e] != 0;
+}
+
+__global__ __launch_bounds__(256) void filter_count_kernel(const uint8_t *__restrict__ keep, const int32_t *__restrict__ map,
+                                                           int64_t nnz, int32_t *__restrict__ blk)
+{
+    __shared__ int wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock;
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int64_t e = base + q * 256 + threadIdx.x;
+        if (e < nnz) cnt += filter_keep(keep, map, e);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of blk[0..nb) in place, blk[nb] = total; one workgroup of 1024 threads walks the array in chunks
+__global__ __launch_bounds__(1024) void filter_scan_blocks_kernel(int32_t *__restrict__ blk, int64_t nb)
+{
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int x = i < nb ? blk[i] : 0;
+        int incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        if (i < nb) blk[i] = before + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blk[nb] = carry_s;
+}
+
+// pos[e] = kept entries before e (all e), kept entries copied to their place
+__global__ __launch_bounds__(256) void filter_scatter_kernel(const uint8_t *__restrict__ keep, const int32_t *__restrict__ map,
+                                                             const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                                             int64_t nnz, const int32_t *__restrict__ blk, int32_t *__restrict__ pos,
+                                                             int32_t *__restrict__ out_col, float *__restrict__ out_val)
+{
+    __shared__ int wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // thread t holds entries base + 8 t .. base + 8 t + 7 (consecutive: one scan over the thread totals orders them)
+    int k[8], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int64_t e = base + (int64_t)threadIdx.x * 8 + q;
+        k[q] = e < nnz ? filter_keep(keep, map, e) : 0;
+        mine += k[q];
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int p = blk[blockIdx.x] + incl - mine;
+    for (int w = 0; w < wave; ++w) p += wsum[w];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int64_t e = base + (int64_t)threadIdx.x * 8 + q;
+        if (e < nnz) {
+            pos[e] = p;
+            if (k[q]) {
+                out_col[p] = colidx[e];
+                out_val[p] = vals[e];
+                ++p;
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) pos[nnz] = blk[gridDim.x];
+}
+
+__global__ void filter_rowptr_kernel(const int64_t *__restrict__ rowptr, int64_t n_rows, const int32_t *__restrict__ pos,
+                                     int64_t *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_rows) out[r] = pos[rowptr[r]];
+}
+
+__global__ void filter_segbegin_kernel(const int64_t *__restrict__ src_rowptr, const int64_t *__restrict__ src_seg_begin,
+                                       const int32_t *__restrict__ seg_row, int64_t n_seg, const int64_t *__restrict__ rowptr,
+                                       int64_t *__restrict__ seg_begin)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_seg) seg_begin[s] = rowptr[seg_row[s]] + (src_seg_begin[s] - src_rowptr[seg_row[s]]);
+}
+
+extern "C" int ngcf_csr_filter(const ngcf_csr_t *src, const uint8_t *keep, const int32_t *map, int64_t nnz_kept,
+                               ngcf_csr_t **dst_inout, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst_inout) return fail(NGCF_ERR_ARG, "ngcf_csr_filter: null argument");
+    if (src->nnz > 0 && !keep) return fail(NGCF_ERR_ARG, "ngcf_csr_filter: null keep flags");
+    if (src->nnz >= ((int64_t)1 << 31) - 1) return fail(NGCF_ERR_ARG, "ngcf_csr_filter: more than 2^31 stored entries");
+    if (nnz_kept > src->nnz) return fail(NGCF_ERR_ARG, "ngcf_csr_filter: nnz_kept exceeds the source's entries");
+    ngcf_csr *d = *dst_inout;
+    const int64_t nb = (src->nnz + kScanBlock - 1) / kScanBlock;
+    if (d && (d->n_rows != src->n_rows || d->n_cols != src->n_cols || d->cap < src->nnz || !d->owns || d->pos_len < src->nnz + 1 ||
+              d->n_seg != src->n_seg)) {
+        ngcf_csr_free(d);
+        d = nullptr;
+        *dst_inout = nullptr;
+    }
+    if (!d) {                                        // first call for this destination: the only allocations
+        d = new ngcf_csr();
+        d->n_rows = src->n_rows;
+        d->n_cols = src->n_cols;
+        d->owns = true;
+        d->cap = std::max<int64_t>(src->nnz, 1);
+        d->pos_len = src->nnz + 1;
+        auto body = [&]() -> int {
+            HIP_TRY(hipMalloc(&d->rowptr, sizeof(int64_t) * (size_t)(d->n_rows + 1)));
+            HIP_TRY(hipMalloc(&d->colidx, sizeof(int32_t) * (size_t)d->cap));
+            HIP_TRY(hipMalloc(&d->vals, sizeof(float) * (size_t)d->cap));
+            HIP_TRY(hipMalloc(&d->pos, sizeof(int32_t) * (size_t)d->pos_len));
+            HIP_TRY(hipMalloc(&d->scan_blk, sizeof(int32_t) * (size_t)(nb + 2)));
+            if (src->n_seg > 0) HIP_TRY(hipMalloc(&d->seg_begin, sizeof(int64_t) * (size_t)src->n_seg));
+            return NGCF_OK;
+        };
+        const int rc = body();
+        if (rc != NGCF_OK) {
+            ngcf_csr_free(d);
+            return rc;
+        }
+    }
+    // plan: the source's segment structure and row groups (a subset of the entries gathers from a subset of the columns)
+    d->seg_len = src->seg_len;
+    d->n_seg = src->n_seg;
+    d->n_heavy = src->n_heavy;
+    d->seg_row = src->seg_row;
+    d->heavy_row = src->heavy_row;
+    d->heavy_seg_ptr = src->heavy_seg_ptr;
+    d->borrows_plan = true;
+    d->filter_src = src;
+    d->groups = src->groups;
+    d->max_row_len = src->max_row_len;               // upper bound
+    d->mode = 0;
+    d->nnz = nnz_kept >= 0 ? nnz_kept : src->nnz;    // exact when the caller knows it (it drew the mask), else an upper bound
+    if (src->nnz == 0) {
+        HIP_TRY(hipMemsetAsync(d->rowptr, 0, sizeof(int64_t) * (size_t)(d->n_rows + 1), stream));
+        *dst_inout = d;
+        return NGCF_OK;
+    }
+    filter_count_kernel<<<dim3((unsigned)nb), 256, 0, stream>>>(keep, map, src->nnz, d->scan_blk);
+    LAUNCH_CHECK();
+    filter_scan_blocks_kernel<<<1, 1024, 0, stream>>>(d->scan_blk, nb);
+    LAUNCH_CHECK();
+    filter_scatter_kernel<<<dim3((unsigned)nb), 256, 0, stream>>>(keep, map, src->colidx, src->vals, src->nnz, d->scan_blk, d->pos,
+                                                                 d->colidx, d->vals);
+    LAUNCH_CHECK();
+    filter_rowptr_kernel<<<(unsigned)((d->n_rows + 1 + 255) / 256), 256, 0, stream>>>(src->rowptr, d->n_rows, d->pos, d->rowptr);
+    LAUNCH_CHECK();
+    if (d->n_seg > 0) {
+        filter_segbegin_kernel<<<(unsigned)((d->n_seg + 255) / 256), 256, 0, stream>>>(src->rowptr, src->seg_begin, d->seg_row, d->n_seg,
+                                                                                     d->rowptr, d->seg_begin);
+        LAUNCH_CHECK();
+    }
+    *dst_inout = d;
+    return NGCF_OK;
+}
+
+extern "C" const int32_t *ngcf_csr_filter_pos(const ngcf_csr_t *c) { return c ? c->pos : nullptr; }
+
+// map_out[pos_t[j]] = pos_l[map[j]] for every kept entry j of the transposed source: where the entries of the thinned transpose
+// sit in the thinned matrix (the map the NEXT layer's thinning of the transpose needs)
+__global__ void filter_remap_kernel(const uint8_t *__restrict__ keep, const int32_t *__restrict__ map, int64_t nnz,
+                                    const int32_t *__restrict__ pos_t, const int32_t *__restrict__ pos_l, int32_t *__restrict__ map_out)
+{
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; j < nnz; j += stride) {
+        const int32_t e = map[j];
+        if (keep[e]) map_out[pos_t[j]] = pos_l[e];
+    }
+}
+
+extern "C" int ngcf_csr_filter_remap(const ngcf_csr_t *dst_t, const uint8_t *keep, const int32_t *map, int64_t n_src_entries,
+                                     const int32_t *pos_l, int32_t *map_out, void *stream)
+{
+    if (!dst_t || !dst_t->pos) return fail(NGCF_ERR_ARG, "ngcf_csr_filter_remap: not a filtered CSR");
+    if (n_src_entries == 0) return NGCF_OK;
+    if (!keep || !map || !pos_l || !map_out || n_src_entries + 1 > dst_t->pos_len)
+        return fail(NGCF_ERR_ARG, "ngcf_csr_filter_remap: bad argument");
+    filter_remap_kernel<<<grid_for(n_src_entries, 256), 256, 0, (hipStream_t)stream>>>(keep, map, n_src_entries, dst_t->pos, pos_l, map_out);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}

@@ -721,8 +721,9 @@ static int dense_dop(int d_out)
 
 extern "C" int64_t ngcf_dense_workspace_bytes(int d_in, int d_out)
 {
-    const int dop = dense_dop(d_out);
+    int dop = dense_dop(d_out);
     if (dop < 0 || d_in <= 0) return -1;
+    dop = std::max(dop, 128);                  // small matrices run narrow layers on 32-row x 128-column tiles
     const int64_t n_chunks = (d_in + NGCF_DC - 1) / NGCF_DC;
     return align_up((n_chunks * NGCF_KC * dop + dop) * (int64_t)sizeof(float), 256) + 256;
 }
@@ -757,8 +758,13 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     hipStream_t stream = (hipStream_t)stream_;
     if (!LE || !Es || !W1 || !b1 || !W2 || !b2 || !norm) return fail(NGCF_ERR_ARG, "layer_dense: null argument");
     if (n_rows < 0 || d_in <= 0 || d_out <= 0) return fail(NGCF_ERR_ARG, "layer_dense: bad sizes");
-    const int dop = dense_dop(d_out);
+    int dop = dense_dop(d_out);
     if (dop < 0) return fail(NGCF_ERR_ARG, "layer_dense: d_out=%d > 512 is not supported", d_out);
+    // Up to 128 output columns on a SMALL matrix (the Seoul graph: 5 940 rows): 128-row tiles are 47 workgroups on 256 CUs and the
+    // 65 -> 65 layer of the reference's own configuration took 28-30 us; 32-row x 128-column tiles (four waves side by side, one
+    // tile each) are 186 workgroups.  From 16 384 rows on (128 tiles of 128 rows) the tall tiles stay.
+    const bool small_rows = dop <= 128 && n_rows <= 16384 && ngcf_opts().dense_small_tiles;
+    if (small_rows) dop = 128;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return fail(NGCF_ERR_ARG, "layer_dense: drop_p=%f not in [0,1)", drop_p);
     if (ldLE < d_in || ldEs < d_in || ldn < d_out || (carry && ldc < d_out) || (drop_mask && ld_mask < d_out))
         return fail(NGCF_ERR_ARG, "layer_dense: leading dimension too small");
@@ -778,7 +784,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const bool direct = direct_env && dop >= 256 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
                         n_rows > 0 && (n_rows <= 8192 || direct_env == 2);
     pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop,
-                                                                                    dop <= 128 ? dop / 32 : 4, Wt, bias2);
+                                                                                    small_rows ? 1 : dop <= 128 ? dop / 32 : 4, Wt, bias2);
     LAUNCH_CHECK();
 #define NGCF_DENSE(RW, CW, NT) \
     return launch_dense<RW, CW, NT>(al, n_rows, LE, ldLE, Es, ldEs, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, \
@@ -818,6 +824,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
         LAUNCH_CHECK();
         return NGCF_OK;
     }
+    if (small_rows) NGCF_DENSE(1, 4, 1);
     switch (dop) {
     case 32: NGCF_DENSE(4, 1, 1);
     case 64: NGCF_DENSE(4, 1, 2);

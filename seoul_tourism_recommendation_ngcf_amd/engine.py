@@ -136,6 +136,35 @@ class LaplacianCSR:
                                                 colidx.numel(), C.byref(out), _stream()))
         return cls(out.value, keep_alive=(rowptr, colidx, vals))
 
+    def filtered(self, keep: torch.Tensor, entry_map: Optional[torch.Tensor] = None, nnz_kept: int = -1,
+                 reuse: Optional["LaplacianCSR"] = None) -> "LaplacianCSR":
+        """Thinned copy on the device (ngcf_csr_filter): the entries e with keep[entry_map[e]] (entry_map None: keep[e]) in this
+        matrix's order - the reference's `sparse_dropout` (NGCF.py:93-100) without a COO rebuild, a host round trip or, when
+        `reuse` (the object a previous call returned for the same source shape) is given, an allocation.  `keep`: device uint8 /
+        bool; `entry_map`: device int32.  The copy borrows this object's segment lists and keeps it alive."""
+        lib = _lib.load()
+        _require_device(keep, "keep flags")
+        if keep.dtype not in (torch.uint8, torch.bool) or not keep.is_contiguous():
+            raise RuntimeError("filtered: keep must be a contiguous uint8 / bool tensor")
+        if entry_map is not None and (entry_map.dtype != torch.int32 or not entry_map.is_contiguous() or entry_map.numel() != self.nnz):
+            raise RuntimeError("filtered: entry_map must be a contiguous int32 tensor with one element per stored entry")
+        if entry_map is None and keep.numel() != self.nnz:
+            raise RuntimeError(f"filtered: {keep.numel()} keep flags for {self.nnz} stored entries")
+        out = C.c_void_p(reuse._h.value if reuse is not None and reuse._h.value else None)
+        with _on(keep.device):
+            rc = lib.ngcf_csr_filter(self._h, _ptr(keep), _ptr(entry_map), int(nnz_kept), C.byref(out), _stream())
+        if reuse is not None:                              # the handle moved into the returned object (or was replaced by the library)
+            reuse._h = C.c_void_p(0 if rc == _lib.OK else (out.value or 0))
+        _lib.check(rc)
+        res = LaplacianCSR(out.value, keep_alive=(self,))
+        res.src_nnz = self.nnz
+        return res
+
+    @property
+    def filter_pos(self) -> int:
+        """Device address of the int32[source nnz + 1] scan `pos` of a filtered copy (position of every kept entry)."""
+        return int(_lib.load().ngcf_csr_filter_pos(self._h) or 0)
+
     # -- misc -----------------------------------------------------------------------------
     def plan(self, seg_len: int):
         _lib.check(_lib.load().ngcf_csr_plan(self._h, int(seg_len), _stream()))
@@ -223,21 +252,25 @@ def spmm(csr: LaplacianCSR, E: torch.Tensor, out: Optional[torch.Tensor] = None,
     return out
 
 
-def spmm_scatter_rows(csr: LaplacianCSR, rows: torch.Tensor, X: torch.Tensor, out: torch.Tensor, edge_drop=None):
-    """out[c, :] += v * X[i, :] for every stored entry (rows[i], c, v) of `csr` (ngcf_spmm_scatter_rows_f32): `L^T . dLE` for a
-    dLE that is non-zero on the rows `rows` only (the last layer's backward).  `edge_drop = (seeds, p)`: device-side node
-    dropout of the forward product."""
+def spmm_t_rows(csr_t: LaplacianCSR, slot: torch.Tensor, X: torch.Tensor, init: Optional[torch.Tensor], out: torch.Tensor,
+                ws: Workspace, edge_drop=None):
+    """out = init + L^T . X for a row-sparse X given compacted (ngcf_spmm_t_rows_f32): `slot` int32[N] maps a matrix row to its
+    row of X / init or -1; every row of `out` is written, every sum runs in a fixed order (no atomics).  `edge_drop = (seeds, p)`:
+    device-side node dropout of the forward product."""
     lib = _lib.load()
     _f32c(X, "X"), _f32c(out, "out")
-    rows = rows.to(device=X.device, dtype=torch.int64).contiguous()
-    if X.shape[0] != rows.numel() or out.shape[0] != csr.n_cols or X.shape[1] != out.shape[1]:
-        raise RuntimeError("spmm_scatter_rows: shape mismatch")
+    if slot.dtype != torch.int32 or slot.numel() != csr_t.n_cols or out.shape[0] != csr_t.n_rows or X.shape[1] != out.shape[1]:
+        raise RuntimeError("spmm_t_rows: shape mismatch")
+    if init is not None and tuple(init.shape) != tuple(X.shape):
+        raise RuntimeError("spmm_t_rows: init must have the shape of X")
     seeds, p = edge_drop if edge_drop is not None else ((), 0.0)
     arr = (C.c_uint64 * max(len(seeds), 1))(*[int(x) & (2 ** 64 - 1) for x in seeds])
+    d = int(X.shape[1])
+    w = ws.get(csr_t.spmm_workspace_bytes(min(d, 512)), X.device)
     with _on(X.device):
-        _lib.check(lib.ngcf_spmm_scatter_rows_f32(csr._h, _ptr(rows), rows.numel(), csr.max_row_len, _ptr(X), _row_major_ld(X, "X"),
-                                                  int(X.shape[1]), _ptr(out), _row_major_ld(out, "out"), float(p), arr, len(seeds),
-                                                  _stream()))
+        _lib.check(lib.ngcf_spmm_t_rows_f32(csr_t._h, _ptr(slot), _ptr(X), _row_major_ld(X, "X"), d, _ptr(init),
+                                            0 if init is None else _row_major_ld(init, "init"), _ptr(out), _row_major_ld(out, "out"),
+                                            float(p), arr, len(seeds), _ptr(w), w.numel(), _stream()))
 
 
 def layer_fused(csr: LaplacianCSR, E_gather: torch.Tensor, E_self: torch.Tensor, W1, b1, W2, b2,

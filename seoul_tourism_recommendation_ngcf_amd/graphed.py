@@ -30,16 +30,24 @@ class _Buffers:
 
 
 class GraphedForward:
-    def __init__(self, model, batch_size: int, year_idx: int = 0, with_neg: bool = True):
+    def __init__(self, model, batch_size: int, year_idx: int = 0, with_neg: bool = True, pos_size: int = None,
+                 neg_size: int = None):
+        """`batch_size`: length of u_id and of the five feature index vectors; `pos_size` / `neg_size`: lengths of pos_item /
+        neg_item when they differ from it (experiment.py:82-91 passes 25 users and 25 candidate items; demo.py one user row per
+        query and every item)."""
         if model.training:
             raise RuntimeError("GraphedForward captures the eval-mode forward: call model.eval() first")
         if model.emb_size % 5 != 0:
             raise RuntimeError("embed_size must be a multiple of 5 (NGCF.py:39-43,114)")
         self.model, self.B, self.year_idx, self.with_neg = model, int(batch_size), int(year_idx), bool(with_neg)
+        self.Bp = self.B if pos_size is None else int(pos_size)
+        self.Bn = (self.B if neg_size is None else int(neg_size)) if self.with_neg else 0
         dev = model._dev()
         self.dev = dev
-        z = lambda: torch.zeros(self.B, dtype=torch.int64, device=dev)  # noqa: E731
-        self.inputs = {k: z() for k in ("u_id", "age", "sex", "month", "day", "dow", "pos_item", "neg_item")}
+        z = lambda n: torch.zeros(n, dtype=torch.int64, device=dev)  # noqa: E731
+        self.inputs = {k: z(self.B) for k in ("u_id", "age", "sex", "month", "day", "dow")}
+        self.inputs["pos_item"] = z(self.Bp)
+        self.inputs["neg_item"] = z(max(self.Bn, 1))
         self.csr = model.laplacian_csr(self.year_idx)      # built (and planned) outside the capture; kept alive here
         self.bufs = _Buffers()
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -78,7 +86,7 @@ class GraphedForward:
                 n = torch.empty(0)
         return all_E, u, p, n
 
-    def __call__(self, u_id, age, sex, month, day, dow, pos_item, neg_item=None, year=None, node_flag=False):
+    def __call__(self, u_id, age, sex, month, day, dow, pos_item, neg_item=None, year=None, node_flag=False, check=True):
         """Same arguments as `NGCF.forward` (keyword calls work); `year` is not inspected - the slice was fixed at
         capture - and `node_flag` must be False."""
         if node_flag:
@@ -87,20 +95,22 @@ class GraphedForward:
         if self.with_neg:
             given["neg_item"] = neg_item
         for k, v in given.items():
-            if v is None or int(v.numel()) != self.B:
-                raise RuntimeError(f"GraphedForward was captured for batches of {self.B}: {k} has "
-                                   f"{0 if v is None else int(v.numel())} elements")
+            want = self.Bp if k == "pos_item" else self.Bn if k == "neg_item" else self.B
+            if v is None or int(v.numel()) != want:
+                raise RuntimeError(f"GraphedForward was captured for {want} elements of {k}: got "
+                                   f"{0 if v is None else int(v.numel())}")
             self.inputs[k].copy_(v, non_blocking=True)
-        return self.replay()
+        return self.replay(check)
 
     def _baked_pointers(self):
         b = self.bufs
         return tuple(t.data_ptr() for t in (b._ws.buf, b._carry[0], b._carry[1], getattr(b, "_e0_pad", None), self.scratch,
                                             self.status) if t is not None)
 
-    def replay(self):
+    def replay(self, check: bool = True):
         """Replay on whatever `self.inputs[...]` (the graph's static int64 index buffers) hold: callers that write their
-        batches straight into those buffers save the eight small copies of `__call__`."""
+        batches straight into those buffers save the eight small copies of `__call__`.  `check=False` skips reading the
+        status word (one host sync); it is sticky, so a later `check_status()` still reports an out-of-range id."""
         if self._baked_pointers() != self._baked:
             raise RuntimeError("GraphedForward: a buffer baked into the captured graph was replaced; capture again")
         self.graph.replay()
@@ -108,7 +118,11 @@ class GraphedForward:
         m = self.model
         m._all_E = all_E
         m.all_users_emb, m.all_items_emb = all_E[:m.n_user], all_E[m.n_user:]       # NGCF.py:148-149
-        if m.check_indices and int(self.status.item()) != 0:
+        if check and m.check_indices:
+            self.check_status()
+        return u, p, n
+
+    def check_status(self):
+        if int(self.status.item()) != 0:
             self.status.zero_()
             raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
-        return u, p, n

@@ -213,8 +213,8 @@ def test_fused_input_gradient_kernel_vs_torch(n_rows, d_in, d_out, strided, dev)
 
 @pytest.mark.parametrize("node_mode", [None, "reference", "device"])
 def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
-    """The last layer's backward on the <= 3 B gathered rows only (compacted dense kernels + ngcf_spmm_scatter_rows_f32 for
-    L^T . dLE) against the dense path (full SpMM on the transposed CSR): same gradients up to the order of the atomic adds;
+    """The last layer's backward on the <= 3 B gathered rows only (compacted dense kernels + ngcf_spmm_t_rows_f32 for
+    L^T . dLE) against the dense path (full SpMM on the transposed CSR): same gradients up to the summation order;
     with and without node dropout (thinned matrices in both modes) and with device-mode message dropout (hash by matrix row)."""
     pkg = _pkg()
     from seoul_tourism_recommendation_ngcf_amd import autograd as ag
@@ -250,8 +250,8 @@ def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
 
 def test_one_layer_model_at_embed_515_trains(dev):
     """A one-layer model at the reference-legal embed_size 515 (515 -> [64]): the last layer's input is 515 wide, beyond the
-    512 columns the row scatter of the row-sparse path keeps in registers - the backward must take the dense path there and
-    give the same gradients as with the row-sparse path switched off."""
+    512 columns a lane of the row-sparse L^T product holds (it runs as two column panels) - same gradients as with the
+    row-sparse path switched off."""
     pkg = _pkg()
     from seoul_tourism_recommendation_ngcf_amd import autograd as ag
     coo = pkg.graphs.synthetic_bipartite(900, 60, 9000, seed=3, device=dev)
@@ -276,3 +276,71 @@ def test_one_layer_model_at_embed_515_trains(dev):
     for k in grads[0]:
         scale = float(grads[1][k].abs().max()) + 1e-12
         np.testing.assert_allclose(grads[0][k].cpu().numpy(), grads[1][k].cpu().numpy(), atol=2e-5 * scale, rtol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("d,heavy,drop", [(65, True, 0.0), (128, True, 0.3), (515, False, 0.0), (600, True, 0.0), (4, False, 0.5)])
+def test_row_sparse_transposed_product_vs_dense(d, heavy, drop, dev):
+    """ngcf_spmm_t_rows_f32: out = init + L^T . X for an X that is non-zero on a few rows only, against the full product on the
+    CSR of L^T with X scattered into a dense matrix (same device-side edge dropout); bit-identical when repeated."""
+    pkg = _pkg()
+    eng = pkg.engine
+    coo = pkg.graphs.synthetic_bipartite(6000, 120 if heavy else 3000, 90000, seed=13, device=dev)   # 120 items: rows cut into segments
+    N = coo["n_user"] + coo["n_item"]
+    order = torch.sort(coo["cols"], stable=True).indices
+    Lt = eng.LaplacianCSR.from_coo(coo["cols"][order], coo["rows"][order], coo["vals"][order], N, N)
+    assert Lt.n_segments > 0 or not heavy                         # the heavy case has rows cut into segments + fix-up
+    g = torch.Generator().manual_seed(d)
+    rows = torch.unique(torch.cat([torch.randint(0, N, (300,), generator=g), torch.arange(N - 5, N)])).to(dev)
+    R = rows.numel()
+    X = torch.randn((R, d), generator=g).to(dev)
+    init = torch.randn((R, d), generator=g).to(dev)
+    slot = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    slot[rows] = torch.arange(R, dtype=torch.int32, device=dev)
+    ed = ([11, 12], drop) if drop else None
+    out = torch.full((N, d + 3), 7.0, device=dev)[:, :d]
+    ws = eng.Workspace()
+    eng.spmm_t_rows(Lt, slot, X, init, out, ws, ed)
+    Xd = torch.zeros((N, d), device=dev)
+    Xd[rows] = X
+    want = eng.spmm(Lt, Xd, ws=ws, edge_drop=None if ed is None else (ed[0], ed[1], True))
+    want[rows] += init
+    scale = max(float(want.abs().max()), 1.0)
+    assert float((out - want).abs().max()) <= 2e-5 * scale
+    again = torch.empty((N, d), device=dev)
+    eng.spmm_t_rows(Lt, slot, X, init, again, ws, ed)
+    assert torch.equal(again, out)
+    eng.spmm_t_rows(Lt, slot, X, None, again, ws, ed)            # without the direct part
+    want[rows] -= init
+    assert float((again - want).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("node_mode", [None, "reference", "device"])
+def test_training_gradients_are_bit_identical_from_run_to_run(node_mode, dev):
+    """Two training steps from the same seed on the same batch (duplicate users and items in it) give bit-identical gradients of
+    every parameter: the gather backward sums duplicates in batch order, L^T . dLE of the row-sparse last layer runs in entry order,
+    the weight gradients add their partials in workgroup order - no float atomics anywhere (the reference on CPU is deterministic too)."""
+    pkg = _pkg()
+    coo = pkg.graphs.synthetic_bipartite(4000, 300, 60000, seed=8, device=dev)
+    num_dict = {"user": 4000, "item": 300, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    B = 256
+    g = torch.Generator().manual_seed(4)
+    r = lambda hi: torch.randint(0, hi, (B,), generator=g).to(dev)  # noqa: E731
+    batch = dict(year=torch.full((B,), 18, device=dev), u_id=r(4000), age=r(76), sex=r(2), month=r(13), day=r(32), dow=r(7),
+                 pos_item=r(300), neg_item=r(300))
+    batch["u_id"][:40] = batch["u_id"][40:80]                      # duplicate users
+    batch["pos_item"][:30] = 0                                     # one heavy item row many times
+    grads = []
+    for _ in range(2):
+        torch.manual_seed(21)
+        model = pkg.NGCF(65, [65, 65, 65], 0.3, [0.1, 0.1, 0.1], 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, B, dev).to(dev)
+        model.train()
+        model.mess_dropout_mode = "device"
+        if node_mode:
+            model.node_dropout_mode = node_mode
+        torch.manual_seed(5)
+        u, p, n = model(node_flag=node_mode is not None, **batch)
+        pkg.BPR(0.025, B)(u, p, n).backward()
+        grads.append({k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None})
+    assert set(grads[0]) == set(grads[1]) and "user_embedding.weight" in grads[0] and "w2_list.2.bias" in grads[0]
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k

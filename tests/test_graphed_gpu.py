@@ -73,3 +73,92 @@ def test_graphed_forward_replays_the_eager_forward(embed, layers, dev):
     ok = _batch(g, B, U, I, dev)                                                  # usable again after the error
     want, got = eager(node_flag=False, **ok), fwd(node_flag=False, **ok)
     assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_unchanged_callers_get_the_graph_replay(dev):
+    """NGCF.forward itself captures and replays (eval mode, torch.no_grad(), node_flag=False): an interleaved sequence of
+    evaluation batches (experiment.py:82-91: 25 users, 25 candidate items, no negatives), scoring batches with negatives,
+    training steps, a load_state_dict and a second year slice gives bit-identical results on a module with auto_graph on and one
+    with it off; replays really happen; a bad id raises within index_check_every calls."""
+    pkg = _pkg()
+    slices = pkg.graphs.seoul_standin(dev, seed=5, n_user=700, n_item=40)
+    lap = [pkg.graphs.to_sparse_coo(s) for s in slices]
+    U, I = 700, 40
+    num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(3)
+    plain = pkg.NGCF(65, [65, 65], 0.3, [0.1, 0.1], 1.0, lap, num_dict, 64, dev).to(dev)
+    auto = copy.deepcopy(plain)
+    auto.lap_list = lap
+    plain.auto_graph = False
+    auto.index_check_every = 2
+    for m in (plain, auto):
+        m.node_dropout_mode = m.mess_dropout_mode = "device"
+    g = torch.Generator().manual_seed(11)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-2) for m in (plain, auto)]
+
+    def same(batch):
+        outs = []
+        for m in (plain, auto):
+            m.eval()
+            with torch.no_grad():
+                outs.append(m(node_flag=False, **batch))
+        for a, b in zip(*outs):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert torch.equal(plain.user_embedding.weight, auto.user_embedding.weight)
+        assert torch.equal(plain.all_items_emb, auto.all_items_emb) and torch.equal(plain.all_users_emb, auto.all_users_emb)
+        return outs[1]
+
+    def train_step(batch):
+        for m, opt in zip((plain, auto), opts):
+            m.train()
+            torch.manual_seed(9)
+            u, p, n = m(node_flag=True, **batch)
+            opt.zero_grad()
+            pkg.BPR(0.025, 64)(u, p, n).backward()
+            opt.step()
+
+    def eval_batch(year=18):                      # experiment.py:82-91
+        b = _batch(g, 25, U, I, dev)
+        b["neg_item"] = torch.empty(0)
+        b["year"] = torch.full((25,), year, device=dev)
+        return b
+
+    held = None
+    for it in range(4):
+        out = same(eval_batch())
+        if it == 2:
+            held = (out[0], out[0].clone())
+    assert auto._graph_calls >= 2 and len(auto._graphs) == 1           # first call of a shape is eager, the third replays
+    assert torch.equal(held[0], held[1])                               # returned tensors are fresh, not the graph's buffers
+    assert same(eval_batch())[2].numel() == 0                          # neg_item empty -> torch.empty(0), NGCF.py:153
+    for _ in range(3):
+        same(_batch(g, 64, U, I, dev))                                 # another shape, with negatives
+    assert len(auto._graphs) == 2
+    for _ in range(2):
+        train_step(_batch(g, 64, U, I, dev))                           # parameters change in place: the graphs stay valid
+    calls = auto._graph_calls
+    for _ in range(3):
+        same(eval_batch())
+        same(_batch(g, 64, U, I, dev))
+    assert auto._graph_calls == calls + 6 and len(auto._graphs) == 2
+    sd = {k: v.clone() + 0.01 for k, v in plain.state_dict().items()}
+    for m in (plain, auto):
+        m.load_state_dict(sd)
+    same(eval_batch())
+    for _ in range(3):
+        same(eval_batch(year=19))                                      # the other year slice: its own graph
+    assert len(auto._graphs) == 3
+    auto.user_embedding.weight = torch.nn.Parameter(auto.user_embedding.weight.detach().clone())   # a replaced parameter: re-capture
+    for _ in range(3):
+        same(eval_batch())
+    assert len(auto._graphs) == 3
+    bad = eval_batch()
+    bad["pos_item"][3] = I
+    auto.eval()
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            for _ in range(3):
+                auto(node_flag=False, **bad)
+    auto.check_indices_now()                                           # the status word was reset by the raise
+    plain.user_embedding.weight.data.copy_(auto.user_embedding.weight.data)
+    same(eval_batch())
