@@ -13,7 +13,8 @@ One "step" = one pass of the hot path: E0 -> 3 x (L.E SpMM + fused dense/LeakyRe
 3 row gathers, fused BPR loss  (NGCF.py:120-156 + bprloss.py:15-22).  The feature injection (NGCF.py:103-115)
 is not part of the step at this width: the reference itself raises for embed_size = 128 (not a multiple of 5).
 Unit of work: one stored nonzero of L processed in one layer; value = n_layers * nnz(L) * steps / time.
-N > 1: the SAME graph is row-partitioned over the ranks (strong scaling), exchange scheme `--exchange`.
+N > 1: the SAME graph is row-partitioned over the ranks (strong scaling), exchange scheme `--exchange`, rows moved by the
+CU-free p2p exchange (copy engines; NGCF_DIST_COLLECTIVES=torch: RCCL collectives) - DESIGN.md 6.
 
 Prints ONE JSON line on rank 0.
 """
@@ -57,9 +58,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--exchange", default="allgather", choices=["bipartite", "allgather"],
-                    help="N > 1: the scheme `value` is measured on (BASELINE config 4 = allgather); the other one is "
-                         "timed as a labelled secondary field of the same line")
+    ap.add_argument("--exchange", default="bipartite", choices=["bipartite", "allgather"],
+                    help="N > 1: the scheme `value` is measured on.  bipartite (default): row partition of the users, item partial "
+                         "sums reduce-scattered to their owners, all-gather of the owned items' carry rows per layer; allgather: the "
+                         "literal scheme of BASELINE config 4 (all-gather of every rank's user and item carry rows per layer, 10x the "
+                         "bytes).  The other one is timed as a labelled secondary field of the same line")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other exchange "
                     "scheme at N > 1; the reference-legal 130-wide first layer through model.forward() at N = 1)")
     ap.add_argument("--seg-len", type=int, default=0, help="override the row-segment length (0 = library default)")
@@ -483,7 +486,7 @@ def main():
                 return crit(u, p, n)
             dt2, loss2, _, _ = timed(step2, False)
             secondary[f"exchange_{other}"] = {"value": edges_per_step_of(len(layers), nnz) * args.steps / dt2, "unit": "edges/s",
-                                              "ms_per_step": dt2 / args.steps * 1e3, "loss": float(loss2),
+                                              "ms_per_step": dt2 / args.steps * 1e3, "loss": float(loss2), "transport": sh2.backend,
                                               "note": ngcf_dist.SCHEME_NOTES[other]}
             del sh2
         except Exception as exc:  # noqa: BLE001
@@ -572,7 +575,9 @@ def main():
                    "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
                    "d": d0, "n_layers": n_layer, "batch": args.batch,
                    "hipgraph": bool(args.hipgraph),
-                   "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, exchange={args.exchange}"},
+                   "parallelism": "single GPU" if world == 1 else
+                   f"row-partition x{world}, exchange={args.exchange} ({ngcf_dist.SCHEME_NOTES[args.exchange]}), transport={sh.backend}"
+                   + (f" (p2p fell back: {sh.p2p_error})" if getattr(sh, "p2p_error", None) else "")},
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),

@@ -134,6 +134,7 @@ struct ngcf_p2p {
     std::vector<char> copy_used;
     hipEvent_t rel_ev[kP2pSlots] = {};
     hipEvent_t fence_ev = nullptr;
+    hipStream_t pub_stream = nullptr;    // carries the host functions of publish()
     P2pStore payload[kP2pPayloads];
     int next_payload = 0;
     uint64_t *pub(int r, int slot) { return shm + (size_t)r * kP2pSlots + slot; }
@@ -162,6 +163,10 @@ extern "C" void ngcf_p2p_destroy(ngcf_p2p_t *p)
     for (hipEvent_t e : p->rel_ev)
         if (e) (void)hipEventDestroy(e);
     if (p->fence_ev) (void)hipEventDestroy(p->fence_ev);
+    if (p->pub_stream) {
+        (void)hipStreamSynchronize(p->pub_stream);
+        (void)hipStreamDestroy(p->pub_stream);
+    }
     if (p->local) (void)hipFree(p->local);
     if (p->shm) munmap(p->shm, p->shm_bytes);
     if (!p->shm_name.empty()) shm_unlink(p->shm_name.c_str());     // every rank tries; the name disappears with the last mapping
@@ -192,6 +197,7 @@ extern "C" int ngcf_p2p_create(int rank, int world, int64_t bytes, const char *s
         }
         for (int s = 0; s < kP2pSlots; ++s) HIP_TRY(hipEventCreateWithFlags(&p->rel_ev[s], hipEventDisableTiming | hipEventReleaseToSystem));
         HIP_TRY(hipEventCreateWithFlags(&p->fence_ev, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&p->pub_stream, hipStreamNonBlocking));
         p->shm_name = shm_name[0] == '/' ? shm_name : std::string("/") + shm_name;
         const int fd = shm_open(p->shm_name.c_str(), O_CREAT | O_RDWR, 0600);
         if (fd < 0) return fail(NGCF_ERR_HIP, "p2p_create: shm_open(%s) failed: %s", p->shm_name.c_str(), strerror(errno));
@@ -247,8 +253,10 @@ extern "C" int ngcf_p2p_publish(ngcf_p2p_t *p, int slot, uint64_t seq, void *str
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!p || slot < 0 || slot >= kP2pSlots) return fail(NGCF_ERR_ARG, "p2p_publish: bad argument");
+    // the host function runs on a stream of its own behind the event: the producer's stream is not held up by the callback
     HIP_TRY(hipEventRecord(p->rel_ev[slot], stream));
-    HIP_TRY(hipLaunchHostFunc(stream, p2p_store_cb, p->store(p->pub(p->rank, slot), seq)));
+    HIP_TRY(hipStreamWaitEvent(p->pub_stream, p->rel_ev[slot], 0));
+    HIP_TRY(hipLaunchHostFunc(p->pub_stream, p2p_store_cb, p->store(p->pub(p->rank, slot), seq)));
     return NGCF_OK;
 }
 

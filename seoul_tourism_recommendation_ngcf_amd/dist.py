@@ -13,19 +13,24 @@ step per layer moves embeddings between ranks.  Two exchange schemes share the s
     by chunk j's asynchronous all-gather, which runs on RCCL's stream while chunk j+1 computes; the layer waits
     only before the next layer's first read.  Bytes received per rank and layer: (W-1)/W * N * d * 4.
 
-``bipartite`` (~10x fewer exchanged bytes)
+``bipartite`` (~10x fewer exchanged bytes; the default of bench.py at N > 1)
     `L = [[0, R], [R^T, 0]]` (matrix.py:49-52): user rows only read item embeddings and vice versa.
-    Users are partitioned, the (small) item block is replicated.  User rows are then fully local; item
-    rows are partial sums over the local users followed by ONE `all_reduce` of `[I, d]` per layer, which
-    overlaps with the user-row kernels.  fp32 summation order differs from the single-GPU engine (tolerance,
-    not bit-exact); all ranks hold bit-identical item rows because the all-reduce result is.
+    Users are partitioned (by stored entries), the (small) item carry is replicated.  User rows are then fully local; item
+    rows are partial sums over the local users, REDUCE-SCATTERED to the rank that owns the item, whose dense half runs
+    there only, followed by an ALL-GATHER of the owned items' carry rows into every rank's item replica - the
+    neighbour embeddings of the next layer's user rows.  Both exchanges overlap with SpMM kernels.  fp32 summation order
+    differs from the single-GPU engine (tolerance, not bit-exact).
 
 A rank never holds more of the graph than its own slabs: they are cut from the interaction triplets (host or
 device tensors, `ShardedPropagation.from_interactions`) or from a row-sorted COO (`from_coo`).
 
+Transport (`NGCF_DIST_COLLECTIVES`): "p2p" (default on device tensors) - the CU-free exchange of include/ngcf_hip.h
+(`ngcf_p2p_*`: every rank's producers write into its own IPC-exported exchange buffer, the peers pull with device-to-device
+copies on copy-engine streams, host threads wait on shared sequence words), which leaves every CU to the L2-swept SpMM;
+"torch" - torch.distributed collectives (RCCL under "nccl"); "cabi" - `ngcf_allgather_rows` on the group's communicator.
+
 Compute is always the HIP engine (`engine.py`); nothing here has a CPU path.  The layout/exchange helpers
 are backend-agnostic tensor plumbing, which is what the world_size-2 `gloo` tests exercise on CPU tensors.
-Forward only: training across ranks (a backward through the exchange) is not built.
 """
 from __future__ import annotations
 
@@ -42,8 +47,9 @@ from . import engine as _eng
 SCHEME_NOTES = {
     "allgather": "row partition (users and items, cut by stored entries) + RCCL all-gather of the carry per layer, user slab "
                  "pipelined in row chunks (BASELINE config 4)",
-    "bipartite": "users partitioned, item block replicated; item rows = partial sums over local users + one all-reduce of "
-                 "[I, d] per layer (an optimisation beside the north-star scheme: ~10x fewer exchanged bytes)",
+    "bipartite": "row partition of the users (cut by stored entries), item carry replicated: item rows = partial sums over the local "
+                 "users, reduce-scattered to the item's owner (dense half there only), then an all-gather of the owned items' carry "
+                 "rows - the neighbour embeddings of the next layer - per layer (~10x fewer exchanged bytes than gathering the users)",
 }
 
 
@@ -141,6 +147,15 @@ class ShardLayout:
         return r, g - ib[r]
 
 
+def padded_item_pos(item: torch.Tensor, item_bounds: Sequence[int], mi: int) -> torch.Tensor:
+    """bipartite scheme: item index -> position in the owner-major padded numbering: item i of owner q (item_bounds[q] <= i <
+    item_bounds[q+1]) sits at q*mi + (i - item_bounds[q]), mi = the largest owner range.  One all-gather of [mi, d] per rank then
+    IS the item replica of the next layer, and a reduce-scatter over [W*mi, d] hands every owner its rows."""
+    ib = torch.tensor(list(item_bounds), device=item.device)
+    q = (torch.searchsorted(ib, item, right=True) - 1).clamp(0, len(item_bounds) - 2)
+    return q * mi + (item - ib[q])
+
+
 def slab_coo(rows, cols, vals, lo: int, hi: int):
     """Entries of rows [lo, hi) of a row-sorted COO, row ids made slab-relative."""
     a, b = (int(x) for x in torch.searchsorted(rows, torch.tensor([lo, hi], device=rows.device)))
@@ -216,6 +231,242 @@ class _CabiAllGather:
 
 
 # ------------------------------------------------------------------------------------------------
+# differentiable exchange steps and layer pieces: the TRAINING path of the sharded engine (experiment.py:57 across ranks)
+# ------------------------------------------------------------------------------------------------
+def _reduce_scatter_rows(full: torch.Tensor, group) -> torch.Tensor:
+    """own[m, d] = sum over ranks of full[rank*m:(rank+1)*m] (gloo has no reduce-scatter: all-reduce + own rows)."""
+    W, r = dist.get_world_size(group), dist.get_rank(group)
+    m = full.shape[0] // W
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((m, full.shape[1]), dtype=full.dtype, device=full.device)
+        dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
+        return out
+    tmp = full.contiguous().clone()
+    dist.all_reduce(tmp, group=group)
+    return tmp[r * m:(r + 1) * m].clone()
+
+
+class AllGatherRows(torch.autograd.Function):
+    """full[W*m, d] = every rank's send[m, d], rank-major.  Adjoint: reduce-scatter of the gradient (every rank used every row)."""
+
+    @staticmethod
+    def forward(ctx, send, group):
+        ctx.group = group
+        full = torch.empty((send.shape[0] * dist.get_world_size(group), send.shape[1]), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(full, send.contiguous(), group=group)
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        return _reduce_scatter_rows(g, ctx.group), None
+
+
+class ReduceScatterRows(torch.autograd.Function):
+    """own[m, d] = sum over ranks of their full[rank*m:(rank+1)*m].  Adjoint: all-gather of the gradient."""
+
+    @staticmethod
+    def forward(ctx, full, group):
+        ctx.group = group
+        return _reduce_scatter_rows(full, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        W = dist.get_world_size(ctx.group)
+        out = torch.empty((g.shape[0] * W, g.shape[1]), dtype=g.dtype, device=g.device)
+        dist.all_gather_into_tensor(out, g.contiguous(), group=ctx.group)
+        return out, None
+
+
+class OwnerRowsSum(torch.autograd.Function):
+    """`owner_rows_sum` with its adjoint.  Every rank computes the SAME loss from the same gathered rows, so the gradient of a
+    served row is that loss's gradient on the rank that served it and nothing elsewhere - no exchange in the backward."""
+
+    @staticmethod
+    def forward(ctx, local_rows, owned, group):
+        ctx.save_for_backward(owned)
+        return owner_rows_sum(local_rows, owned, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        (owned,) = ctx.saved_tensors
+        return torch.where(owned[:, None], g, torch.zeros((), dtype=g.dtype, device=g.device)), None, None
+
+
+class SpmmFn(torch.autograd.Function):
+    """LE = A . E on the HIP SpMM with A^T given as a second CSR: the backward is the product with that one."""
+
+    @staticmethod
+    def forward(ctx, E, csr, csr_t, ws):
+        ctx.csr_t, ctx.ws = csr_t, ws
+        return _eng.spmm(csr, E.detach(), ws=ws)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = g.shape[1]
+        gp = torch.empty((g.shape[0], (d + 31) // 32 * 32), dtype=torch.float32, device=g.device)[:, :d]
+        gp.copy_(g)                                                # 128-byte aligned rows for the gather
+        return _eng.spmm(ctx.csr_t, gp, ws=ctx.ws), None, None, None
+
+
+class DenseLayerFn(torch.autograd.Function):
+    """(carry, norm) of one layer's dense half (NGCF.py:131-146, eval-mode: no message dropout) for a slab of rows, with the
+    hand-written backward kernels of autograd.py (normalise / LeakyReLU backward, MFMA weight and input gradients)."""
+
+    @staticmethod
+    def forward(ctx, LE, E, W1, b1, W2, b2, ws):
+        n, d_out = LE.shape[0], W1.shape[0]
+        ld = (d_out + 31) // 32 * 32
+        carry = torch.empty((n, ld), dtype=torch.float32, device=LE.device)[:, :d_out]
+        norm = torch.empty((n, d_out), dtype=torch.float32, device=LE.device)
+        if n:
+            _eng.layer_dense(LE.detach(), E.detach(), W1.detach(), b1.detach(), W2.detach(), b2.detach(), carry, norm, ws)
+        ctx.ws = ws
+        ctx.save_for_backward(LE.detach(), E.detach(), carry, W1.detach(), W2.detach())
+        return carry, norm
+
+    @staticmethod
+    def backward(ctx, dC, dN):
+        from . import autograd as ag
+        LE, E, carry, W1, W2 = ctx.saved_tensors
+        n, d_in = LE.shape
+        if n == 0:
+            z = torch.zeros_like
+            return z(LE), z(E), z(W1), W1.new_zeros(W1.shape[0]), z(W2), W2.new_zeros(W2.shape[0]), None
+        dM = ag._bwd_pre(dN.contiguous() if dN is not None else None, dC.contiguous() if dC is not None else None, carry,
+                         _eng.LEAKY_SLOPE, 0.0, 0)
+        gW, gb = ag._bwd_weight(dM, LE, E, ctx.ws)
+        dLE, dE = ag._bwd_input(dM, W1, W2, LE, E, ctx.ws)
+        return dLE, dE, gW[:, :d_in].contiguous(), 2.0 * gb, gW[:, d_in:].contiguous(), gb, None
+
+
+class _SumGrads(torch.autograd.Function):
+    """Identity on the (replicated) parameters; its backward adds every parameter's gradient over the ranks - the one all-reduce
+    per parameter and step of data-parallel training (each rank contributes the rows it owns)."""
+
+    @staticmethod
+    def forward(ctx, group, *params):
+        ctx.group = group
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = []
+        for gr in grads:
+            if gr is None:
+                out.append(None)
+                continue
+            gr = gr.contiguous()
+            dist.all_reduce(gr, group=ctx.group)
+            out.append(gr)
+        return (None, *out)
+
+
+class _DevMem:
+    """`__cuda_array_interface__` carrier: a torch tensor over device memory the library allocated (the exchange buffer)."""
+
+    def __init__(self, ptr: int, n_floats: int):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(n_floats),), "typestr": "<f4", "version": 2}
+
+
+class P2PExchange:
+    """The CU-free exchange of include/ngcf_hip.h (`ngcf_p2p_*`): one exchange buffer per rank, peers pull from it with
+    device-to-device copies on copy-engine streams, host threads do the waiting.  All ranks of `group` must live on one node
+    (IPC handles + POSIX shared memory).  `floats(offset, n)` gives a tensor over this rank's buffer: producers write there."""
+
+    TIMEOUT_MS = float(os.environ.get("NGCF_P2P_TIMEOUT_MS", "60000"))
+
+    def __init__(self, group, device, n_floats: int):
+        lib = _lib.load()
+        self.group, self.dev = group, torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_floats = int(n_floats)
+        tok = [os.urandom(8).hex() if self.rank == 0 else None]
+        dist.broadcast_object_list(tok, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.name = f"ngcf_p2p_{tok[0]}"
+        h = C.c_void_p()
+        with _eng._on(self.dev):
+            _lib.check(lib.ngcf_p2p_create(self.rank, self.world, max(self.n_floats, 64) * 4, self.name.encode(), C.byref(h)))
+        self._h = h
+        mine = (C.c_char * 64)()
+        _lib.check(lib.ngcf_p2p_handle(self._h, mine))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(mine.raw), group=group)
+        blob = (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(handles))
+        with _eng._on(self.dev):
+            _lib.check(lib.ngcf_p2p_connect(self._h, blob))
+        self.base = int(lib.ngcf_p2p_local(self._h))
+        self._mem = torch.as_tensor(_DevMem(self.base, max(self.n_floats, 64)), device=self.dev)
+        assert self._mem.data_ptr() == self.base and self._mem.dtype == torch.float32
+        self.seq = {}                      # slot -> last published / expected step
+        dist.barrier(group=group)          # everyone is connected before the first pull
+
+    def floats(self, offset: int, n: int) -> torch.Tensor:
+        assert 0 <= offset and offset + n <= self.n_floats
+        return self._mem[offset:offset + n]
+
+    def publish(self, slot: int, seq: int):
+        _lib.check(_lib.load().ngcf_p2p_publish(self._h, slot, seq, _eng._stream()))
+
+    def pull(self, peer: int, slot: int, seq: int, src_off_floats: int, dst: torch.Tensor):
+        """dst (contiguous, this device) <- rank `peer`'s exchange buffer [src_off, src_off + dst.numel()), once it published `seq`."""
+        assert dst.is_contiguous() and dst.dtype == torch.float32
+        _lib.check(_lib.load().ngcf_p2p_pull(self._h, peer, slot, seq, src_off_floats * 4, C.c_void_p(dst.data_ptr()),
+                                             dst.numel() * 4, self.TIMEOUT_MS))
+
+    def ack(self, peer: int, slot: int, seq: int):
+        _lib.check(_lib.load().ngcf_p2p_ack(self._h, peer, slot, seq))
+
+    def wait_acks(self, slot: int, seq: int):
+        _lib.check(_lib.load().ngcf_p2p_wait_acks(self._h, slot, seq, self.TIMEOUT_MS))
+
+    def fence(self):
+        _lib.check(_lib.load().ngcf_p2p_fence(self._h, _eng._stream()))
+
+    def join(self):
+        _lib.check(_lib.load().ngcf_p2p_join(self._h, _eng._stream()))
+
+    def peers_from(self, start: int):
+        """All ranks, beginning after `start` (every rank starts its pulls at another peer: the links are used evenly)."""
+        return [(start + 1 + q) % self.world for q in range(self.world)]
+
+    def selftest(self) -> bool:
+        """Every rank writes a pattern, publishes it, pulls every peer's and compares; True on every rank iff it worked everywhere."""
+        ok = 1
+        try:
+            n = 1024
+            probe = self.floats(0, n)
+            probe.copy_(torch.arange(n, dtype=torch.float32, device=self.dev) + 1000.0 * self.rank)
+            self.publish(63, 1)
+            got = torch.empty((self.world, n), dtype=torch.float32, device=self.dev)
+            for q in self.peers_from(self.rank):
+                self.pull(q, 63, 1, 0, got[q])
+                self.ack(q, 63, 1)
+            self.join()
+            torch.cuda.synchronize(self.dev)
+            want = torch.arange(n, dtype=torch.float32, device=self.dev)[None] + 1000.0 * torch.arange(self.world, device=self.dev)[:, None]
+            ok = int(torch.equal(got, want))
+            self.wait_acks(63, 1)
+        except Exception:  # noqa: BLE001
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.dev)
+            self._mem = None
+            _lib.load().ngcf_p2p_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
 # sharded propagation on the HIP engine
 # ------------------------------------------------------------------------------------------------
 class ShardedPropagation:
@@ -279,22 +530,38 @@ class ShardedPropagation:
         U, I, W, r = self.U, self.I, self.world, self.rank
         swept_mode = int(os.environ.get("NGCF_SPMM_MODE", "3"))
         to_dev = lambda t: t.to(dev, non_blocking=True)            # noqa: E731
+        self.backend = self._pick_backend(group, dev)
         if mode == "bipartite":
-            self.ub = even_bounds(0, U, W)
+            cnt = torch.cat([deg_u.to("cpu", torch.int64), deg_i.to("cpu", torch.int64)])
+            self.ub = balanced_bounds(cnt, 0, U, W)                # user ranges with ~equal stored entries
+            self.ib = even_bounds(0, I, W)                         # item OWNER ranges (item indices): reduce + dense + carry of those rows
+            self.mi = mi = max(max(self.ib[q + 1] - self.ib[q] for q in range(W)), 1)
+            self.PI = W * mi                                       # padded item numbering: item i of owner q sits at q*mi + (i - ib[q])
             lo, hi = self.ub[r], self.ub[r + 1]
-            self.nu = hi - lo
+            self.nu, self.ni = hi - lo, self.ib[r + 1] - self.ib[r]
             (ur, uc, uv), _ = cut(lo, hi, 0, 0)
             ur, uc, uv = to_dev(ur), to_dev(uc), to_dev(uv)
-            # user rows: local users x all items (columns renumbered to item ids)
-            self.csr_u = _eng.LaplacianCSR.from_coo(ur - lo, uc - U, uv, self.nu, I)
+            pos = self.item_pos(uc - U)
+            # user rows: local users x all items (replicated item carry, padded numbering)
+            self.csr_u = _eng.LaplacianCSR.from_coo(ur - lo, pos, uv, self.nu, self.PI)
             # item rows restricted to local user columns -> partial sums: the transpose of the same slice
-            order = torch.sort(uc, stable=True).indices
-            self.csr_it = _eng.LaplacianCSR.from_coo(uc[order] - U, ur[order] - lo, uv[order], I, max(self.nu, 1))
-            # the item partial sums run alone on the GPU (the all-reduce starts after them): L2-swept kernel where it
-            # pays.  The user rows overlap with the all-reduce; a persistent one-workgroup-per-CU kernel must not
-            # share the CUs with the collective's kernels, so they stay on the row-wise kernels.
+            order = torch.sort(pos, stable=True).indices
+            self.csr_it = _eng.LaplacianCSR.from_coo(pos[order], ur[order] - lo, uv[order], self.PI, max(self.nu, 1))
+            # The item partial sums run alone on the GPU: L2-swept kernel where it pays.  The user rows overlap with the exchange:
+            # over copy engines (p2p) nothing else occupies a CU and they are swept too; beside an RCCL kernel the persistent
+            # one-workgroup-per-CU sweep loses 3.4-4x (profiles/r02_c4_rank_lab.txt), so there they stay on the row-wise kernels.
             self.csr_it.set_mode(swept_mode)
+            if self.backend == "p2p" or W == 1:
+                self.csr_u.set_mode(swept_mode)
             self.local_nnz = self.csr_u.nnz + self.csr_it.nnz
+            widths = [model.emb_size] + list(model.weight_size)
+            ld = lambda d: (d + 31) // 32 * 32                     # noqa: E731
+            self._ld_in, self._ld_out = max(ld(d) for d in widths[:-1]), max(ld(d) for d in widths[1:])
+            if self.backend == "p2p":
+                # exchange buffer: [partial sums of all items] x 2, [carry rows of the owned items] x 2 (two steps in turn)
+                self._off_part = [0, self.PI * self._ld_in]
+                self._off_carry = [2 * self.PI * self._ld_in, 2 * self.PI * self._ld_in + mi * self._ld_out]
+                self.p2p = self._open_p2p(group, dev, 2 * self.PI * self._ld_in + 2 * mi * self._ld_out)
         else:
             cnt = torch.cat([deg_u.to("cpu", torch.int64), deg_i.to("cpu", torch.int64)])
             ub = balanced_bounds(cnt, 0, U, W)
@@ -315,14 +582,62 @@ class ShardedPropagation:
             # the item slab runs with no collective in flight (the layer's gathers have all been waited for): swept kernel
             # where it pays.  With one chunk and one rank nothing overlaps the user slab either.
             self.csr_i.set_mode(swept_mode)
-            if W == 1:
+            if W == 1 or self.backend == "p2p":
                 for c in self.csr_u:
                     c.set_mode(swept_mode)
             self.local_nnz = sum(c.nnz for c in self.csr_u) + self.csr_i.nnz
+            if self.backend == "p2p":
+                # exchange buffer: the carry rows this rank produces (item slab + every user chunk), two layers in turn
+                widths = [model.emb_size] + list(model.weight_size)
+                self._ld_out = max((d + 31) // 32 * 32 for d in widths[1:])
+                per_layer = (lay.mi + chunks * lay.mc) * self._ld_out
+                self._off_send = [0, per_layer]
+                self.p2p = self._open_p2p(group, dev, 2 * per_layer)
         self._bufs = {}
         self._cabi = None
-        if os.environ.get("NGCF_DIST_COLLECTIVES") == "cabi" and dist.get_backend(group) == "nccl":
+        self._last_pub = {}
+        self._calls = 0
+        if self.backend == "cabi":
             self._cabi = _CabiAllGather(group, dev)
+
+    def item_pos(self, item: torch.Tensor) -> torch.Tensor:
+        """bipartite scheme: item index -> position in the padded item numbering (owner-major)."""
+        return padded_item_pos(item, self.ib, self.mi)
+
+    def _pick_backend(self, group, dev) -> str:
+        """How the rows travel: "p2p" = copy engines + host-side waiting (ngcf_p2p_*, one node), "torch" = torch.distributed
+        collectives (RCCL under the nccl backend), "cabi" = ngcf_allgather_rows on the process group's communicator.
+        NGCF_DIST_COLLECTIVES picks one; the default is p2p on device tensors with more than one rank (it falls back to "torch"
+        on every rank together if the exchange cannot be set up or its self-test fails)."""
+        want = os.environ.get("NGCF_DIST_COLLECTIVES", "p2p" if self.world > 1 else "torch")
+        if want == "cabi" and dist.get_backend(group) != "nccl":
+            want = "torch"
+        if want not in ("p2p", "torch", "cabi"):
+            raise ValueError("NGCF_DIST_COLLECTIVES must be p2p, torch or cabi")
+        if want == "p2p" and (self.world == 1 or torch.device(dev).type != "cuda"):
+            want = "torch"
+        return want
+
+    def _open_p2p(self, group, dev, n_floats):
+        ex, ok = None, 1
+        try:
+            ex = P2PExchange(group, dev, n_floats)
+        except Exception as exc:  # noqa: BLE001
+            ok = 0
+            self.p2p_error = repr(exc)[:300]
+        t = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        if int(t.item()) == 1 and not ex.selftest():
+            t.zero_()
+            self.p2p_error = "self-test failed"
+        if int(t.item()) != 1:                                    # every rank takes the same decision
+            if ex is not None:
+                ex.close()
+            self.backend = "torch"
+            for c in ([self.csr_u] if self.mode == "bipartite" else self.csr_u):     # beside RCCL kernels: row-wise again
+                c.set_mode(0)
+            return None
+        return ex
 
     def _buf(self, name, shape):
         b = self._bufs.get(name)
@@ -350,37 +665,167 @@ class ShardedPropagation:
 
     # -- propagation ----------------------------------------------------------------------------
     def propagate(self):
-        return self._propagate_bipartite() if self.mode == "bipartite" else self._propagate_allgather()
+        """(all_E rows of this rank's users, all_E rows of its items).  When autograd is recording and a parameter of the model
+        requires a gradient (and the scheme is `bipartite`), the differentiable path runs: `loss.backward()` then leaves in every
+        parameter's `.grad` the gradient summed over all ranks (experiment.py:57 across GPUs)."""
+        m = self.model
+        if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
+            if self.mode != "bipartite":
+                raise RuntimeError("training across ranks is built for the bipartite exchange scheme (mode='bipartite')")
+            return self._propagate_bipartite_train()
+        with torch.no_grad():
+            return self._propagate_bipartite() if self.mode == "bipartite" else self._propagate_allgather()
+
+    def _propagate_bipartite_train(self):
+        """The bipartite scheme as a composition of differentiable pieces: `SpmmFn` (the two CSRs of a rank are each other's
+        transposes), `DenseLayerFn` (hand-written backward kernels), `ReduceScatterRows` / `AllGatherRows` (each the other's
+        adjoint).  Eval-mode semantics (no dropout).  The exchange uses torch.distributed collectives in both directions.
+        Gradients: every rank's backward yields the contribution of the rows it owns; `_SumGrads` adds them over the ranks, so
+        after `loss.backward()` all ranks hold the same, complete `.grad` for every parameter - as after a single-GPU step."""
+        m, g = self.model, self.group
+        r, W, mi, PI = self.rank, self.world, self.mi, self.PI
+        lo, nu, ni = self.ub[r], self.nu, self.ni
+        n_layer = m.n_layer
+        # parameters enter through one Function whose backward all-reduces their gradients (once per step)
+        params = [m.user_embedding.weight, m.item_embedding.weight] + [l.weight for l in m.w1_list] + [l.bias for l in m.w1_list] + \
+                 [l.weight for l in m.w2_list] + [l.bias for l in m.w2_list]
+        outs = _SumGrads.apply(g, *params)
+        uw, iw = outs[0], outs[1]
+        w1, b1 = outs[2:2 + n_layer], outs[2 + n_layer:2 + 2 * n_layer]
+        w2, b2 = outs[2 + 2 * n_layer:2 + 3 * n_layer], outs[2 + 3 * n_layer:]
+        eu = uw[lo:lo + nu]
+        # item replica in the padded numbering (a gather of the replicated table; padding rows read item 0 and are never used)
+        src = torch.zeros(PI, dtype=torch.int64, device=self.dev)
+        src[self.item_pos(torch.arange(self.I, device=self.dev))] = torch.arange(self.I, device=self.dev)
+        ei = iw[src]
+        own = slice(r * mi, r * mi + ni)
+        blocks_u, blocks_i = [eu], [ei[own]]
+        for k in range(n_layer):
+            part = SpmmFn.apply(eu, self.csr_it, self.csr_u, self.ws)               # item partial sums over the local users
+            le_own = ReduceScatterRows.apply(part, g)                                # [mi, d]: the owned items, summed over ranks
+            le_u = SpmmFn.apply(ei, self.csr_u, self.csr_it, self.ws)               # user rows, fully local
+            cu, nrm_u = DenseLayerFn.apply(le_u, eu, w1[k], b1[k], w2[k], b2[k], self.ws)
+            ci, nrm_i = DenseLayerFn.apply(le_own[:ni], ei[own], w1[k], b1[k], w2[k], b2[k], self.ws)
+            blocks_u.append(nrm_u)
+            blocks_i.append(nrm_i)
+            if k + 1 < n_layer:
+                send = torch.zeros((mi, ci.shape[1]), dtype=torch.float32, device=self.dev)
+                send = torch.cat([ci, send[ni:]], 0) if ni < mi else ci
+                ei = AllGatherRows.apply(send, g)
+            eu = cu
+        self.allE_u, self.allE_i = torch.cat(blocks_u, 1), torch.cat(blocks_i, 1)
+        return self.allE_u, self.allE_i
 
     def _propagate_bipartite(self):
+        """Users partitioned, item block replicated.  Per layer:  A  item partial sums over the local users (swept SpMM on the
+        transposed user slab)  ->  reduce-scatter: every rank receives the partial sums of the items it OWNS and adds them in
+        rank order  ->  B  user rows (fully local, overlaps with that exchange)  ->  C  dense half for the owned items only  ->
+        all-gather of their carry rows into every rank's item replica (overlaps with the next layer's A).  The exchanged bytes
+        per rank and layer are 2 x (W-1)/W x I x d x 4 (C3, W = 8: 2 x 45 MB) against (W-1)/W x N x d x 4 (493 MB) for the all-gather
+        of users; nothing is computed twice (r02 ran the item dense replicated after an all-reduce)."""
         m = self.model
         w1, b1, w2, b2 = self._params()
         widths = [m.emb_size] + [int(w.shape[0]) for w in w1]
         D, n_layer = sum(widths), len(w1)
-        lo = self.ub[self.rank]
-        nu, I = self.nu, self.I
+        r, W, mi, PI = self.rank, self.world, self.mi, self.PI
+        lo, nu, ni = self.ub[r], self.nu, self.ni
+        ld = lambda d: (d + 31) // 32 * 32                         # noqa: E731
         allE_u = torch.empty((nu, D), dtype=torch.float32, device=self.dev)       # this rank's users
-        allE_i = torch.empty((I, D), dtype=torch.float32, device=self.dev)        # all items, replicated
+        allE_i = torch.empty((ni, D), dtype=torch.float32, device=self.dev)       # the items this rank owns
         d0 = widths[0]
+        iw = m.item_embedding.weight.detach()
         _eng.copy_rows(m.user_embedding.weight.detach()[lo:lo + nu], allE_u[:, :d0])
-        _eng.copy_rows(m.item_embedding.weight.detach(), allE_i[:, :d0])
-        eu, ei = allE_u[:, :d0], allE_i[:, :d0]
+        _eng.copy_rows(iw[self.ib[r]:self.ib[r + 1]], allE_i[:, :d0])
+        # layer-0 item replica from the replicated parameter table (padded numbering): local copies, no communication
+        ei = self._buf(("ei", 0), (PI, ld(d0)))[:, :d0]
+        for q in range(W):
+            n_q = self.ib[q + 1] - self.ib[q]
+            if n_q:
+                _eng.copy_rows(iw[self.ib[q]:self.ib[q + 1]], ei[q * mi:q * mi + n_q])
+        eu = allE_u[:, :d0]
+        if d0 % 4 or D % 4:                                        # rows of all_E are not 16-byte aligned: an aligned copy to gather from
+            eu = self._buf(("eu0",), (nu, ld(d0)))[:, :d0]
+            _eng.copy_rows(m.user_embedding.weight.detach()[lo:lo + nu], eu)
+        ex = self.p2p if self.backend == "p2p" else None
+        self._calls += 1
+        base = self._calls * (n_layer + 1)
+        gloo = dist.get_backend(self.group) != "nccl"
         off = d0
+        pending = None                                             # the all-gather of the previous layer's item carry
         for k in range(n_layer):
             d_in, d_out = widths[k], widths[k + 1]
             last = k == n_layer - 1
-            # 1) item rows: partial sums over the local users, then one all-reduce (async on RCCL's stream)
-            part = self._buf(("part", k % 2), (I, d_in))
-            _eng.spmm(self.csr_it, eu, out=part, ws=self.ws)
-            work = dist.all_reduce(part, group=self.group, async_op=True)
-            # 2) user rows: fully local (gathers from the replicated item block) - overlaps with the all-reduce
-            cu = None if last else self._buf(("cu", k % 2), (nu, d_out))
+            seq, par = base + k + 1, k % 2
+            sp, sc = 2 * par, 2 * par + 1                          # sequence slots: partial sums / carry of this parity
+            if ex is not None:
+                ex.fence()                                         # copies of this layer start after the previous layer's readers
+                # -- A: item partial sums over the local users, into the exchange buffer
+                ex.wait_acks(sp, self._last_pub.get(sp, 0))
+                part = ex.floats(self._off_part[par], PI * ld(d_in)).view(PI, ld(d_in))[:, :d_in]
+                _eng.spmm(self.csr_it, eu, out=part, ws=self.ws)
+                ex.publish(sp, seq)
+                self._last_pub[sp] = seq
+                # -- the previous layer's item carry arrives while A runs
+                if pending is not None:
+                    nxt_ei, pseq, psc, pld = pending
+                    for q in ex.peers_from(r):
+                        ex.pull(q, psc, pseq, self._off_carry[(k - 1) % 2], nxt_ei[q * mi:(q + 1) * mi])
+                        ex.ack(q, psc, pseq)
+                    ex.join()
+                    ei = nxt_ei[:, :d_in]
+                    pending = None
+            else:
+                if pending is not None:
+                    pending.wait()
+                part = self._buf(("part", k), (PI, ld(d_in)))[:, :d_in]
+                _eng.spmm(self.csr_it, eu, out=part, ws=self.ws)
+            # -- B: user rows, fully local (gathers from the item replica); overlaps with the reduce-scatter
+            if ex is None:
+                le_own = self._buf(("le_own", k), (mi, ld(d_in)))
+                full_part = self._bufs[("part", k)]
+                if gloo:                                           # gloo has no reduce-scatter: all-reduce and keep the own rows
+                    work = dist.all_reduce(full_part, group=self.group, async_op=True)
+                else:
+                    work = dist.reduce_scatter_tensor(le_own, full_part, group=self.group, async_op=True)
+            cu = None if last else self._buf(("cu", k), (nu, ld(d_out)))[:, :d_out]
             _eng.layer_fused(self.csr_u, ei, eu, w1[k], b1[k], w2[k], b2[k], cu, allE_u[:, off:off + d_out], self.ws)
-            # 3) dense half for ALL items (replicated: every rank gets bit-identical rows)
-            work.wait()
-            ci = None if last else self._buf(("ci", k % 2), (I, d_out))
-            _eng.layer_dense(part, ei, w1[k], b1[k], w2[k], b2[k], ci, allE_i[:, off:off + d_out], self.ws)
-            eu, ei = cu, ci
+            # -- reduce-scatter: the partial sums of the owned items from every rank, added in rank order
+            if ex is not None:
+                slots = self._buf(("slots", k), (W, mi, ld(d_in)))
+                for q in ex.peers_from(r):
+                    ex.pull(q, sp, seq, self._off_part[par] + r * mi * ld(d_in), slots[q])
+                    ex.ack(q, sp, seq)
+                ex.join()
+                le_own = self._buf(("le_own", k), (mi, ld(d_in)))
+                with _eng._on(self.dev):
+                    _lib.check(_lib.load().ngcf_sum_slots_f32(_eng._ptr(slots), mi * ld(d_in), W, mi * ld(d_in), _eng._ptr(le_own),
+                                                              _eng._stream()))
+            else:
+                work.wait()
+                if gloo:
+                    le_own = full_part[r * mi:(r + 1) * mi]
+            # -- C: dense half for the owned items; their carry rows go to every rank's replica of the next layer
+            if last:
+                ci = None
+            elif ex is not None:
+                ex.wait_acks(sc, self._last_pub.get(sc, 0))
+                ci = ex.floats(self._off_carry[par], mi * ld(d_out)).view(mi, ld(d_out))
+            else:
+                ci = self._buf(("ci", k), (mi, ld(d_out)))
+            if ni:
+                _eng.layer_dense(le_own[:ni, :d_in], ei[r * mi:r * mi + ni], w1[k], b1[k], w2[k], b2[k],
+                                 None if last else ci[:ni, :d_out], allE_i[:, off:off + d_out], self.ws)
+            if not last:
+                nxt_ei = self._buf(("ei", k + 1), (PI, ld(d_out)))
+                if ex is not None:
+                    ex.publish(sc, seq)
+                    self._last_pub[sc] = seq
+                    pending = (nxt_ei, seq, sc, ld(d_out))         # pulled at the top of the next layer, under its A
+                else:
+                    pending = dist.all_gather_into_tensor(nxt_ei, ci, group=self.group, async_op=True)
+                    # (waited for before the next layer's swept A: an RCCL kernel beside the sweep costs more than the wait)
+                    ei = nxt_ei[:, :d_out]
+            eu = cu
             off += d_out
         self.allE_u, self.allE_i = allE_u, allE_i
         return allE_u, allE_i
@@ -414,6 +859,8 @@ class ShardedPropagation:
                                full[lay.item_pos(q):lay.item_pos(q) + lay.n_items_of(q)])
         off = d0
         first_row = [lay.chunk_range(r, j)[0] - lay.ub[r] for j in range(Cn)]      # chunk j's rows inside allE_u
+        if self.backend == "p2p":
+            return self._allgather_layers_p2p(full, allE_u, allE_i, widths, first_row, w1, b1, w2, b2)
         for k in range(n_layer):
             d_out = widths[k + 1]
             last = k == n_layer - 1
@@ -443,6 +890,68 @@ class ShardedPropagation:
         self.allE_u, self.allE_i = allE_u, allE_i
         return allE_u, allE_i
 
+    def _allgather_layers_p2p(self, full, allE_u, allE_i, widths, first_row, w1, b1, w2, b2):
+        """The layers of the all-gather scheme over the CU-free exchange: every piece of carry rows this rank produces (item slab,
+        then the user chunks) is written into its exchange buffer and published; the peers - and this rank itself - pull it
+        into their replica of the next layer while the following piece computes.  No kernel of the exchange shares the CUs, so
+        every piece runs on the L2-swept kernel where its plan pays."""
+        lay, r, W, Cn, ex = self.layout, self.rank, self.world, self.chunks, self.p2p
+        n_layer = len(w1)
+        nu, ni = self.nu, self.ni
+        self._calls += 1
+        base = self._calls * (n_layer + 1)
+        off = widths[0]
+        ldo = lambda d: (d + 31) // 32 * 32                        # noqa: E731
+        for k in range(n_layer):
+            d_out = widths[k + 1]
+            last = k == n_layer - 1
+            seq, par = base + k + 1, k % 2
+            ld = ldo(d_out)
+            nxt = None if last else self._buf(("fullp", (k + 1) % 2 + 1), (lay.P, ld))
+            if not last:
+                ex.fence()
+            # pieces: 0 = item slab, 1 + j = user chunk j; their rows inside the exchange buffer and inside every replica
+            send_off = [self._off_send[par]] + [self._off_send[par] + (lay.mi + j * lay.mc) * ld for j in range(Cn)]
+            rows = [lay.mi] + [lay.mc] * Cn
+
+            def region(q, piece):
+                a = lay.item_pos(q) if piece == 0 else lay.user_pos(q, piece - 1)
+                return nxt[a:a + rows[piece]]
+
+            def pull_piece(piece):
+                slot = par * (Cn + 1) + piece
+                for q in ex.peers_from(r):
+                    ex.pull(q, slot, seq, send_off[piece], region(q, piece))
+                    ex.ack(q, slot, seq)
+
+            for piece in range(Cn + 1):
+                slot = par * (Cn + 1) + piece
+                send = None
+                if not last:
+                    ex.wait_acks(slot, self._last_pub.get(slot, 0))
+                    send = ex.floats(send_off[piece], rows[piece] * ld).view(rows[piece], ld)
+                if piece == 0:
+                    _eng.layer_fused(self.csr_i, full, full[lay.item_pos(r):lay.item_pos(r) + ni], w1[k], b1[k], w2[k], b2[k],
+                                     None if last else send[:ni, :d_out], allE_i[:, off:off + d_out], self.ws)
+                else:
+                    j = piece - 1
+                    n_j, pos = lay.n_users_of(r, j), lay.user_pos(r, j)
+                    _eng.layer_fused(self.csr_u[j], full, full[pos:pos + n_j], w1[k], b1[k], w2[k], b2[k],
+                                     None if last else send[:n_j, :d_out],
+                                     allE_u[first_row[j]:first_row[j] + n_j, off:off + d_out], self.ws)
+                if not last:
+                    ex.publish(slot, seq)
+                    self._last_pub[slot] = seq
+                    if piece > 0:
+                        pull_piece(piece - 1)                      # the previous piece travels while this one computes
+            if not last:
+                pull_piece(Cn)
+                ex.join()                                          # only now: the next layer reads the whole replica
+                full = nxt[:, :d_out]
+            off += d_out
+        self.allE_u, self.allE_i = allE_u, allE_i
+        return allE_u, allE_i
+
     # -- gathers + BPR (NGCF.py:151-156, bprloss.py:15-22) ---------------------------------------
     def gather(self, u_id: torch.Tensor, pos_item: torch.Tensor, neg_item: torch.Tensor):
         """(u, pos, neg) `[B, D]` on every rank.  Rows are served by their owning rank and summed."""
@@ -452,16 +961,24 @@ class ShardedPropagation:
         def served(table, owner, local, n_rows):
             mine = owner == self.rank
             idx = torch.where(mine, local, torch.zeros_like(local))
+            if table.requires_grad:                                # training path: torch indexing carries the gradient
+                rows = table[idx] if n_rows else torch.zeros((idx.numel(), table.shape[1]), device=dev)
+                return OwnerRowsSum.apply(rows, mine, self.group)
             rows = _eng.gather_rows(table, idx, self.status, 0, max(n_rows, 1)) if n_rows else \
                 torch.zeros((idx.numel(), table.shape[1]), device=dev)
             return owner_rows_sum(rows, mine, self.group)
 
         if self.mode == "bipartite":
-            ub = torch.tensor(self.ub, device=dev)
+            ub, ib = torch.tensor(self.ub, device=dev), torch.tensor(self.ib, device=dev)
             ow = (torch.searchsorted(ub, u_id, right=True) - 1).clamp(0, self.world - 1)
             u = served(self.allE_u, ow, u_id - ub[ow], self.nu)
-            p = _eng.gather_rows(self.allE_i, pos_item, self.status)
-            n = _eng.gather_rows(self.allE_i, neg_item.to(dev), self.status) if len(neg_item) > 0 else torch.empty(0)
+            ow = (torch.searchsorted(ib, pos_item, right=True) - 1).clamp(0, self.world - 1)
+            p = served(self.allE_i, ow, pos_item - ib[ow], self.ni)
+            n = torch.empty(0)
+            if len(neg_item) > 0:
+                neg_item = neg_item.to(dev)
+                ow = (torch.searchsorted(ib, neg_item, right=True) - 1).clamp(0, self.world - 1)
+                n = served(self.allE_i, ow, neg_item - ib[ow], self.ni)
         else:
             lay = self.layout
             ow, loc = lay.owner_of_user(u_id)

@@ -85,3 +85,59 @@ def test_c4_eight_rank_partition_simulated_on_one_gpu():
     np.testing.assert_allclose(got[::997].cpu().numpy(), want[::997].cpu().numpy(), atol=2e-5, rtol=2e-3)
     err = (got - want).abs().max()
     assert float(err) <= 2e-5 + 2e-3 * float(want.abs().max())
+
+
+def _c4_worker(rank, world, port, mode, ret):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NGCF_P2P_TIMEOUT_MS="60000")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import seoul_tourism_recommendation_ngcf_amd as pkg
+        from seoul_tourism_recommendation_ngcf_amd import dist as nd
+        dev = torch.device("cuda:0")
+        U, I, d = 1_000_000, 100_000, 128
+        u, i, w = pkg.graphs.synthetic_interactions(U, I, 50_000_000, seed=2603, device=dev)
+        num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+        torch.manual_seed(2603)
+        coo = pkg.graphs._normalise(u, i, w, U, I)
+        coo.update({"n_user": U, "n_item": I})
+        model = pkg.NGCF(d, [d, d, d], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, 1024, dev).to(dev).eval()
+        with torch.no_grad():
+            want = model.propagate(0).clone()                      # the single-GPU engine on the same graph and parameters
+        del coo
+        model._csr_cache.clear()
+        torch.cuda.empty_cache()
+        sh = nd.ShardedPropagation.from_interactions(model, u, i, w, mode=mode, device=dev)     # the product code itself
+        del u, i, w
+        assert sh.backend == "p2p", getattr(sh, "p2p_error", None)
+        au, ai = sh.propagate()
+        au, ai = sh.propagate()
+        torch.cuda.synchronize()
+        if mode == "bipartite":
+            wu, wi = want[sh.ub[rank]:sh.ub[rank + 1]], want[U + sh.ib[rank]:U + sh.ib[rank + 1]]
+        else:
+            wu, wi = want[sh.layout.ub[rank]:sh.layout.ub[rank + 1]], want[sh.layout.ib[rank]:sh.layout.ib[rank + 1]]
+        tol = 2e-5 + 2e-3 * float(want.abs().max())
+        ok = au.shape == wu.shape and ai.shape == wi.shape and float((au - wu).abs().max()) <= tol and float((ai - wi).abs().max()) <= tol
+        ok = ok and torch.equal(au[:, :d], wu[:, :d])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["bipartite", "allgather"])
+def test_c4_sharded_propagation_itself_two_ranks_share_the_gpu(mode):
+    """`ShardedPropagation.from_interactions` + `propagate` themselves (not a re-implementation of their loop) on the full C3 graph,
+    3 layers, two ranks sharing the one GPU (process group gloo, rows exchanged by the CU-free p2p exchange through IPC-mapped
+    buffers): every rank's rows of all_E equal the single-GPU engine's."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_c4_worker, args=(2, port, mode, ret), nprocs=2, join=True)
+        assert dict(ret) == {0: True, 1: True}

@@ -137,31 +137,130 @@ def _cpu_worker(rank, world, port, ret):
         local = got_i[torch.where(mine, loc, torch.zeros_like(loc))]
         assert torch.allclose(nd.owner_rows_sum(local, mine), want[U:][it], atol=1e-6)
 
-        # ---- bipartite scheme: users partitioned, items replicated, one all-reduce per layer
-        eb = nd.even_bounds(0, U, world)
+        # ---- bipartite scheme (dist._propagate_bipartite does exactly this): users partitioned by stored entries, item carry
+        # replicated in the owner-major padded numbering; per layer a reduce-scatter of the item partial sums to the owners
+        # (gloo has none: all-reduce + own rows), the dense half for the owned items only, an all-gather of their carry rows
+        eb = nd.balanced_bounds(cnt, 0, U, world)
+        ob = nd.even_bounds(0, I, world)
+        mi = max(ob[q + 1] - ob[q] for q in range(world))
+        PI = world * mi
+        ipos = nd.padded_item_pos(torch.arange(I), ob, mi)
+        assert ipos.unique().numel() == I and int(ipos.max()) < PI
         lo, hi = eb[rank], eb[rank + 1]
-        n_ue = int(torch.searchsorted(rows, torch.tensor([U])))
-        ur, uc, uv = nd.slab_coo(rows, cols, vals, lo, hi)
-        Lu = torch.sparse_coo_tensor(torch.stack([ur, uc - U]), uv, (hi - lo, I))
-        ir, ic, iv = rows[n_ue:] - U, cols[n_ue:], vals[n_ue:]
-        sel = (ic >= lo) & (ic < hi)
-        Lit = torch.sparse_coo_tensor(torch.stack([ir[sel], ic[sel] - lo]), iv[sel], (I, hi - lo))
-        eu, ei = E0[lo:hi], E0[U:]
-        bu, bi = [eu], [ei]
+        (sur, suc, suv), _ = nd.cut_slabs(iu, ii, iv, U, lo, hi, 0, 0)
+        pos = nd.padded_item_pos(suc - U, ob, mi)
+        Lu = torch.sparse_coo_tensor(torch.stack([sur - lo, pos]), suv, (hi - lo, PI))
+        Lit = torch.sparse_coo_tensor(torch.stack([pos, sur - lo]), suv, (PI, hi - lo))
+        eu = E0[lo:hi]
+        ei = torch.full((PI, d0), float("nan"))
+        ei[ipos] = E0[U:]
+        own = slice(rank * mi, rank * mi + (ob[rank + 1] - ob[rank]))
+        bu, bi = [eu], [E0[U + ob[rank]:U + ob[rank + 1]]]
         for k in range(len(layers)):
-            part = torch.mm(Lit, eu)
+            part = torch.mm(Lit, eu)                                # partial sums of ALL items over the local users
             work = dist.all_reduce(part, async_op=True)
-            cu, nu_ = _dense_oracle(torch.mm(Lu, ei), eu, w1[k], b1[k], w2[k], b2[k])
+            cu, nu_ = _dense_oracle(torch.mm(Lu, torch.nan_to_num(ei, nan=0.0)), eu, w1[k], b1[k], w2[k], b2[k])
             work.wait()
-            ci, ni_ = _dense_oracle(part, ei, w1[k], b1[k], w2[k], b2[k])
+            ci, ni_ = _dense_oracle(part[own], ei[own], w1[k], b1[k], w2[k], b2[k])      # the owned items only
+            send = torch.full((mi, layers[k]), float("nan"))
+            send[:ci.shape[0]] = ci
+            nxt = torch.full((PI, layers[k]), float("nan"))
+            nd.allgather_rows(nxt, send)
+            assert not torch.isnan(nxt[ipos]).any()
             bu.append(nu_)
             bi.append(ni_)
-            eu, ei = cu, ci
+            eu, ei = cu, nxt
         assert torch.allclose(torch.cat(bu, 1), want[lo:hi], atol=1e-6)
-        assert torch.allclose(torch.cat(bi, 1), want[U:], atol=1e-6)
+        assert torch.allclose(torch.cat(bi, 1), want[U + ob[rank]:U + ob[rank + 1]], atol=1e-6)
         ret[rank] = 1
     finally:
         dist.destroy_process_group()
+
+
+def _cpu_train_worker(rank, world, port, ret):
+    """Backward through the exchange on CPU tensors: the differentiable exchange steps of dist.py (AllGatherRows, ReduceScatterRows,
+    OwnerRowsSum, _SumGrads) drive the bipartite scheme with the ORACLE's arithmetic (torch CPU ops + torch autograd) per slab; every
+    parameter's gradient on every rank must equal the unsharded oracle's."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seoul_tourism_recommendation_ngcf_amd import dist as nd, graphs
+        U, I, d0, layers = 240, 31, 12, (12, 8)
+        iu, ii, iw_ = graphs.synthetic_interactions(U, I, 2500, seed=6, device="cpu")
+        iv, deg_u, deg_i = nd.laplacian_values(iu, ii, iw_, U, I)
+        coo = _toy_graph(U, I, 2500, seed=6)
+        N = U + I
+        L = torch.sparse_coo_tensor(torch.stack([coo["rows"], coo["cols"]]), coo["vals"], (N, N))
+        g = torch.Generator().manual_seed(3)
+        E0 = torch.randn((N, d0), generator=g)
+        w1, b1, w2, b2 = _params(d0, layers, 4)
+        u_id, pos, neg = (torch.randint(0, hi, (40,), generator=g) for hi in (U, I, I))
+
+        def leaves():
+            ps = [E0[:U].clone(), E0[U:].clone()] + [t.clone() for t in w1 + b1 + w2 + b2]
+            return [p.requires_grad_(True) for p in ps]
+
+        # unsharded oracle
+        ref = leaves()
+        n = len(layers)
+        all_E = orc.propagate_torch(L, ref[0], ref[1], ref[2:2 + n], ref[2 + n:2 + 2 * n], ref[2 + 2 * n:2 + 3 * n], ref[2 + 3 * n:])
+        ou, op, on = orc.gather_torch(all_E, U, u_id, pos, neg)
+        orc.bpr_torch(ou, op, on, 0.025, 40).backward()
+        # sharded, same arithmetic per slab
+        cnt = torch.cat([deg_u, deg_i])
+        eb = nd.balanced_bounds(cnt, 0, U, world)
+        ob = nd.even_bounds(0, I, world)
+        mi = max(ob[q + 1] - ob[q] for q in range(world))
+        PI = world * mi
+        lo, hi = eb[rank], eb[rank + 1]
+        ni = ob[rank + 1] - ob[rank]
+        (sur, suc, suv), _ = nd.cut_slabs(iu, ii, iv, U, lo, hi, 0, 0)
+        ppos = nd.padded_item_pos(suc - U, ob, mi)
+        Lu = torch.sparse_coo_tensor(torch.stack([sur - lo, ppos]), suv, (hi - lo, PI))
+        Lit = torch.sparse_coo_tensor(torch.stack([ppos, sur - lo]), suv, (PI, hi - lo))
+        mine = leaves()
+        outs = nd._SumGrads.apply(None, *mine)
+        uw, iw = outs[0], outs[1]
+        pw1, pb1, pw2, pb2 = outs[2:2 + n], outs[2 + n:2 + 2 * n], outs[2 + 2 * n:2 + 3 * n], outs[2 + 3 * n:]
+        src = torch.zeros(PI, dtype=torch.int64)
+        src[nd.padded_item_pos(torch.arange(I), ob, mi)] = torch.arange(I)
+        eu, ei = uw[lo:hi], iw[src]
+        own = slice(rank * mi, rank * mi + ni)
+        bu, bi = [eu], [ei[own]]
+        for k in range(n):
+            le_own = nd.ReduceScatterRows.apply(torch.mm(Lit, eu), None)
+            cu, nu_ = _dense_oracle(torch.mm(Lu, ei), eu, pw1[k], pb1[k], pw2[k], pb2[k])
+            ci, ni_ = _dense_oracle(le_own[:ni], ei[own], pw1[k], pb1[k], pw2[k], pb2[k])
+            bu.append(nu_)
+            bi.append(ni_)
+            if k + 1 < n:
+                ei = nd.AllGatherRows.apply(torch.cat([ci, torch.zeros((mi - ni, ci.shape[1]))], 0), None)
+            eu = cu
+        allE_u, allE_i = torch.cat(bu, 1), torch.cat(bi, 1)
+        assert torch.allclose(allE_u, all_E[lo:hi].detach(), atol=1e-6) and torch.allclose(allE_i, all_E[U + ob[rank]:U + ob[rank + 1]].detach(), atol=1e-6)
+
+        def served(table, bounds, idx):
+            b = torch.tensor(bounds)
+            ow = (torch.searchsorted(b, idx, right=True) - 1).clamp(0, world - 1)
+            own_ = ow == rank
+            loc = torch.where(own_, idx - b[ow], torch.zeros_like(idx))
+            rows = table[loc] if table.shape[0] else torch.zeros((idx.numel(), table.shape[1]))
+            return nd.OwnerRowsSum.apply(rows, own_, None)
+        su, sp, sn = served(allE_u, eb, u_id), served(allE_i, ob, pos), served(allE_i, ob, neg)
+        orc.bpr_torch(su, sp, sn, 0.025, 40).backward()
+        for a, b_ in zip(mine, ref):
+            assert a.grad is not None and torch.allclose(a.grad, b_.grad, atol=1e-6 + 1e-5 * float(b_.grad.abs().max())), (a.shape,)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_backward_through_the_exchange_on_gloo_cpu(world):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_cpu_train_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {r: 1 for r in range(world)}
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -199,10 +298,11 @@ def test_layout_and_bounds_single_process():
 # ------------------------------------------------------------------------------------------------
 # GPU: the real sharded HIP path, two ranks on one device
 # ------------------------------------------------------------------------------------------------
-def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    if cabi:
-        os.environ["NGCF_DIST_COLLECTIVES"] = "cabi"              # ngcf_allgather_rows on the process group's communicator
+def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False, collectives="torch"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NGCF_P2P_TIMEOUT_MS="20000")
+    # how the rows travel: "p2p" = the CU-free exchange (IPC-mapped buffers, copy streams, host-side waiting), "torch" =
+    # torch.distributed collectives, "cabi" = ngcf_allgather_rows on the process group's communicator
+    os.environ["NGCF_DIST_COLLECTIVES"] = "cabi" if cabi else collectives
     if backend == "nccl":
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
@@ -226,10 +326,15 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False):
             assert sum(c.nnz for c in sh.csr_u) + sh.csr_i.nnz <= coo["nnz"] // world + coo["nnz"] // 10
         else:
             sh = nd.ShardedPropagation.from_coo(model, coo["rows"], coo["cols"], coo["vals"], mode=mode)
-        au, ai = sh.propagate()
+        assert sh.backend == ("cabi" if cabi else collectives if world > 1 else "torch"), (sh.backend, getattr(sh, "p2p_error", None))
+        first = sh.propagate()
+        first = (first[0].clone(), first[1].clone())
+        au, ai = sh.propagate()                                    # a second pass re-uses every buffer and both exchange regions
+        assert torch.equal(au, first[0]) and torch.equal(ai, first[1])
         if mode == "bipartite":
             lo, hi = sh.ub[rank], sh.ub[rank + 1]
-            ok = torch.allclose(au, want[lo:hi], atol=2e-5, rtol=2e-3) and torch.allclose(ai, want[U:], atol=2e-5, rtol=2e-3)
+            ok = torch.allclose(au, want[lo:hi], atol=2e-5, rtol=2e-3) and \
+                torch.allclose(ai, want[U + sh.ib[rank]:U + sh.ib[rank + 1]], atol=2e-5, rtol=2e-3)
         else:
             lay = sh.layout
             ok = torch.allclose(au, want[lay.ub[rank]:lay.ub[rank + 1]], atol=2e-5, rtol=2e-3) and \
@@ -250,11 +355,16 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,world", [("bipartite", 2), ("allgather", 2), ("bipartite", 3), ("allgather", 3)])
-def test_sharded_propagation_ranks_share_one_gpu(mode, world):
+@pytest.mark.parametrize("mode,world,collectives", [("bipartite", 2, "p2p"), ("allgather", 2, "p2p"), ("bipartite", 3, "p2p"),
+                                                    ("allgather", 3, "p2p"), ("bipartite", 2, "torch"), ("allgather", 2, "torch"),
+                                                    ("bipartite", 3, "torch"), ("allgather", 3, "torch")])
+def test_sharded_propagation_ranks_share_one_gpu(mode, world, collectives):
+    """Both exchange schemes over both transports, 2 and 3 ranks sharing the one GPU (process group gloo): "p2p" exchanges the rows
+    through IPC-mapped exchange buffers pulled with device-to-device copies (include/ngcf_hip.h, ngcf_p2p_*), "torch" through
+    torch.distributed; every rank's rows equal the single-GPU engine's, two passes give the same bits."""
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_gpu_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
+        mp.spawn(_gpu_worker, args=(world, _free_port(), mode, ret, "gloo", False, collectives), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}
 
 
@@ -277,3 +387,54 @@ def test_allgather_rows_c_entry_point_on_the_process_groups_communicator():
         ret = mgr.dict()
         mp.spawn(_gpu_worker, args=(1, _free_port(), "allgather", ret, "nccl", True), nprocs=1, join=True)
         assert dict(ret) == {0: True}
+
+
+def _gpu_train_worker(rank, world, port, ret):
+    """`loss.backward()` through the sharded propagation (experiment.py:57 across ranks): every parameter's gradient on every rank
+    equals the single-GPU engine's gradient on the same graph, parameters and batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NGCF_DIST_COLLECTIVES="torch")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import seoul_tourism_recommendation_ngcf_amd as pkg
+        from seoul_tourism_recommendation_ngcf_amd import dist as nd
+        dev = torch.device("cuda:0")
+        U, I, B = 5000, 330, 96
+        coo = pkg.graphs.synthetic_bipartite(U, I, 70000, seed=4, device=dev)
+        num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+        g = torch.Generator().manual_seed(12)
+        u_id, pos, neg = (torch.randint(0, hi, (B,), generator=g).to(dev) for hi in (U, I, I))
+        u_id[:10] = u_id[10:20]                                    # duplicates in the batch
+        grads = []
+        for sharded in (False, True):
+            torch.manual_seed(7)
+            model = pkg.NGCF(65, [65, 64], None, None, 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, B, dev).to(dev).eval()
+            crit = pkg.BPR(0.025, B)
+            if sharded:
+                sh = nd.ShardedPropagation.from_coo(model, coo["rows"], coo["cols"], coo["vals"], mode="bipartite")
+                sh.propagate()
+                u, p, n = sh.gather(u_id, pos, neg)
+            else:
+                all_E = model.propagate(0)
+                u, p, n = all_E[:U][u_id], all_E[U:][pos], all_E[U:][neg]
+            loss = crit(u, p, n)
+            loss.backward()
+            grads.append((float(loss), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}))
+        assert abs(grads[0][0] - grads[1][0]) <= 1e-5 * abs(grads[0][0])
+        assert set(grads[0][1]) == set(grads[1][1]) and "user_embedding.weight" in grads[0][1] and "w2_list.1.bias" in grads[0][1]
+        ok = True
+        for k, want in grads[0][1].items():
+            got = grads[1][1][k]
+            scale = float(want.abs().max()) + 1e-12
+            ok = ok and bool(((got - want).abs() <= 2e-3 * scale * 1e-1 + 2e-3 * want.abs()).all())
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_backward_through_the_sharded_propagation_ranks_share_one_gpu(world):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gpu_train_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {r: True for r in range(world)}

@@ -65,30 +65,43 @@ for W in (1, 2, 4, 8):
           f"all-gather: {recv / 1e6:.0f} MB received per rank and layer = {recv / 153e9 * 1e3 / max(W - 1, 1) * (W - 1) / 7 if W > 1 else 0:.2f} ms if all 7 links "
           f"of 153 GB/s were busy, {recv / 153e9 * 1e3:.2f} ms over one link", flush=True)
 
-# ---- the bipartite scheme: users partitioned, items replicated; per rank: item partial sums over the local users (small table,
-# high re-use), the local user rows (gather from the replicated item block), the dense half for the local users and for ALL items
-print("bipartite scheme, one rank's compute (the [I, d] all-reduce of 51 MB per layer left out):", flush=True)
+# ---- the bipartite scheme (r03 form, dist._propagate_bipartite): users partitioned by stored entries, item carry replicated in the
+# owner-major padded numbering; per rank and layer: item partial sums over the local users (small table, high re-use), the local
+# user rows (gather from the item replica), the sum of the W partial-sum slices of the OWNED items and their dense half (I/W rows)
+print("bipartite scheme (reduce-scatter of the item partial sums to their owners, sharded item dense, all-gather of the owned carry "
+      "rows), one rank's compute, exchange left out:", flush=True)
+import ctypes as C  # noqa: E402
+from seoul_tourism_recommendation_ngcf_amd import _lib  # noqa: E402
+lib = _lib.load()
 base = None
 for W in (1, 2, 4, 8):
-    eb = nd.even_bounds(0, U, W)
+    eb = nd.balanced_bounds(cnt, 0, U, W)
+    ob = nd.even_bounds(0, I, W)
+    mi = max(ob[q + 1] - ob[q] for q in range(W))
+    PI = W * mi
     r = W // 2
     lo, hi = eb[r], eb[r + 1]
     (ur, uc, uv), _ = nd.cut_slabs(u, i, v, U, lo, hi, 0, 0)
-    csr_u = eng.LaplacianCSR.from_coo(ur - lo, uc - U, uv, hi - lo, I)
-    order = torch.sort(uc, stable=True).indices
-    csr_it = eng.LaplacianCSR.from_coo(uc[order] - U, ur[order] - lo, uv[order], I, hi - lo)
+    pos = nd.padded_item_pos(uc - U, ob, mi)
+    csr_u = eng.LaplacianCSR.from_coo(ur - lo, pos, uv, hi - lo, PI)
+    order = torch.sort(pos, stable=True).indices
+    csr_it = eng.LaplacianCSR.from_coo(pos[order], ur[order] - lo, uv[order], PI, hi - lo)
     csr_it.set_mode(3)
-    csr_u.set_mode(3 if (W == 1 or os.environ.get("LAB_SWEPT_CHUNKS") == "1") else 0)
+    csr_u.set_mode(0 if os.environ.get("LAB_ROWWISE_USERS") == "1" else 3)     # swept: what runs over the CU-free p2p exchange
     eu = torch.randn((hi - lo, d), device=dev) * 0.1
-    ei = torch.randn((I, d), device=dev) * 0.1
-    part = torch.empty((I, d), device=dev)
+    ei = torch.randn((PI, d), device=dev) * 0.1
+    part = torch.empty((PI, d), device=dev)
+    slots = torch.randn((W, mi, d), device=dev) * 0.1
+    le_own = torch.empty((mi, d), device=dev)
     cu, nu_ = torch.empty((hi - lo, d), device=dev), torch.empty((hi - lo, d), device=dev)
-    ci, ni_ = torch.empty((I, d), device=dev), torch.empty((I, d), device=dev)
+    ci, ni_ = torch.empty((mi, d), device=dev), torch.empty((mi, d), device=dev)
 
     def layer_b():
         eng.spmm(csr_it, eu, out=part, ws=ws)
         eng.layer_fused(csr_u, ei, eu, W1, b1, W2, b2, cu, nu_, ws)
-        eng.layer_dense(part, ei, W1, b1, W2, b2, ci, ni_, ws)
+        _lib.check(lib.ngcf_sum_slots_f32(C.c_void_p(slots.data_ptr()), mi * d, W, mi * d, C.c_void_p(le_own.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        eng.layer_dense(le_own, ei[r * mi:(r + 1) * mi], W1, b1, W2, b2, ci, ni_, ws)
     for _ in range(3):
         layer_b()
     torch.cuda.synchronize()
@@ -100,5 +113,7 @@ for W in (1, 2, 4, 8):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     base = base or ms
+    sent = 2 * (W - 1) * mi * d * 4
     print(f"W={W}: rank {r}: {csr_u.nnz + csr_it.nnz} stored entries, swept rows [{csr_it.swept_rows}, {csr_u.swept_rows}]; compute {ms:.3f} ms per layer "
-          f"({n_layer * ms:.2f} ms per step, {base / ms:.2f}x the W=1 rank)", flush=True)
+          f"({n_layer * ms:.2f} ms per step, {base / ms:.2f}x the W=1 rank); exchange: {sent / 1e6:.1f} MB received per rank and layer "
+          f"(partial-sum slices + carry rows) = {sent / max(W - 1, 1) / 153e9 * 1e3:.3f} ms with every peer on its own 153 GB/s link", flush=True)
