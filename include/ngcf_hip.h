@@ -266,6 +266,12 @@ int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp
  * gathered positions sorted by row, stable - duplicates add up in batch order; int64 device arrays).  No atomics. */
 int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr, int64_t n_seg,
                               float *out, int64_t ldo, void *stream);
+/* The distinct rows among M <= 8 192 gathered positions, in one launch: idx int64[M] (rows of all_E, each < 2^50) ->
+ * order int64[M] (the positions 0..M-1 sorted by row, equal rows in batch order), rows int64[<= M] (distinct, ascending),
+ * segptr int64[<= M + 1] (group bounds inside `order`), n_rows int64[1].  All device arrays sized for M (segptr M + 1).
+ * Feeds ngcf_segment_sum_rows_f32; replaces torch.unique + sort + cumsum (a dozen library launches) on the training step. */
+int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t *order, int64_t *rows, int64_t *segptr, int64_t *n_rows,
+                          void *stream);
 /* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block; NULL = zero:
  * the rows no gather touched), dC (gradient of the carry from the next layer, may be NULL; not both) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,

@@ -11,6 +11,7 @@ with the module on the CPU raises.
 from __future__ import annotations
 
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -104,6 +105,8 @@ class NGCF(nn.Module):
         self._graphs = {}                        # (sizes, year slice, parameter addresses) -> GraphedForward, most recent last
         self._graph_calls = 0
         self._graph_seen = set()
+        self._plist = None
+        self._year_tag, self._year_idx = None, 0
 
     # ------------------------------------------------------------------------------------
     # engine plumbing
@@ -341,8 +344,35 @@ class NGCF(nn.Module):
     # forward (NGCF.py:102-156)
     # ------------------------------------------------------------------------------------
     def _graph_key(self, dev, sizes, year_idx):
-        ptrs = tuple(p.data_ptr() for p in self.parameters())
+        # the parameter tensors' addresses: from a cached list of the Parameter objects (walking the module tree costs 25 us, more
+        # than the replay's launch) that is rebuilt after train() / eval(), .to() / .cuda(), load_state_dict() and every 16th call
+        if self._plist is None or self._graph_calls % 16 == 0:
+            self._plist = list(self.parameters())
+        ptrs = tuple(p.data_ptr() for p in self._plist)
         return (sizes, year_idx, id(self.lap_list[year_idx]), str(dev), ptrs)
+
+    def train(self, mode: bool = True):
+        self._plist = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plist = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._plist = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _year_index(self, year: torch.Tensor) -> int:
+        """`year.unique()[0] % 18` (NGCF.py:117) = the smallest year of the batch, read back from the device once per tensor:
+        the same tensor OBJECT passed again unmodified (same version counter) needs no second host sync."""
+        if not year.numel():
+            return 0
+        ref, ver = self._year_tag if self._year_tag is not None else (None, -1)
+        if ref is None or ref() is not year or ver != year._version:    # identity of the OBJECT (an address alone is re-used by the allocator)
+            self._year_idx = int(year.min().item() % 18)
+            self._year_tag = (weakref.ref(year), year._version)
+        return self._year_idx
 
     def _forward_graphed(self, dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item):
         """The inference forward as a hipGraph replay (graphed.GraphedForward): captured on first use per (index vector lengths,
@@ -351,7 +381,7 @@ class NGCF(nn.Module):
         tensors like the eager path.  Out-of-range ids raise IndexError at the latest `index_check_every` calls later (the status
         word is sticky; `check_indices_now()` reads it on demand)."""
         from .graphed import GraphedForward
-        year_idx = int(year.min().item() % 18) if year.numel() else 0   # == year.unique()[0] % 18, NGCF.py:117
+        year_idx = self._year_index(year)
         sizes = (len(u_id), len(pos_item), len(neg_item))
         for v in (age, sex, month, day, dow):
             if len(v) != sizes[0]:
@@ -370,11 +400,14 @@ class NGCF(nn.Module):
             g = GraphedForward(self, sizes[0], year_idx, with_neg=sizes[2] > 0, pos_size=sizes[1], neg_size=sizes[2] or None)
         self._graphs[key] = g
         self._graph_calls += 1
-        u, p, n = g(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item,
-                    neg_item=neg_item if sizes[2] > 0 else None, node_flag=False, check=False)
+        g.load_inputs(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item,
+                      neg_item=neg_item if sizes[2] > 0 else None)
+        u, p, n = g.replay(check=False)
         if self.check_indices and self._graph_calls % max(1, int(self.index_check_every)) == 0:
             g.check_status()
-        return u.clone(), p.clone(), (n.clone() if sizes[2] > 0 else torch.empty(0))
+        outs = [torch.empty_like(u), torch.empty_like(p)] + ([torch.empty_like(n)] if sizes[2] > 0 else [])
+        torch._foreach_copy_(outs, [u, p] + ([n] if sizes[2] > 0 else []))         # fresh tensors like the eager path, one launch
+        return outs[0], outs[1], (outs[2] if sizes[2] > 0 else torch.empty(0))
 
     def check_indices_now(self):
         """Raise IndexError if any graph-replayed forward since the last check saw an out-of-range id."""
@@ -403,7 +436,7 @@ class NGCF(nn.Module):
                  self.day_emb.weight.data, self.dow_emb.weight.data),
                 (age, sex, month, day, dow), u_id, self.emb_ratio, self._scratch_buf(dev), status)
 
-        year_idx = int(year.min().item() % 18) if year.numel() else 0   # == year.unique()[0] % 18, NGCF.py:117
+        year_idx = self._year_index(year)                              # == year.unique()[0] % 18, NGCF.py:117
         self.propagate(year_idx, bool(node_flag))
 
         u_idx = u_id.to(device=dev, dtype=torch.int64).contiguous()

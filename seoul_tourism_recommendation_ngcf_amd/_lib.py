@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ngcf_bpr_workspace_bytes": (_i64, [_i64]),
     "ngcf_bpr_fused_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp]),
     "ngcf_bpr_backward_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "ngcf_rows_sort_unique": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ngcf_segment_sum_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_layer_bwd_pre_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _f32, _f32, _u64, _vp, _i64,
                                          _vp, _vp, _i64, _vp]),

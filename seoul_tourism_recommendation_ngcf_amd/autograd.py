@@ -28,28 +28,24 @@ def _padded_rows(n: int, d: int, dev) -> torch.Tensor:
     return torch.empty((n, (d + 31) // 32 * 32), dtype=torch.float32, device=dev)[:, :d]
 
 
+def _alloc_all_E(N: int, widths, dev) -> torch.Tensor:
+    """all_E [N, D] for the `cat` of NGCF.py:147.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130,
+    515), so D is usually not a multiple of 4 and contiguous rows would not be 16-byte aligned.  Then the rows are padded to a
+    multiple of 32 floats (a [N, D] view of a [N, ld] buffer: every row starts on a 128-byte line), so that block 0 - E0, which the
+    first layer gathers from - serves the float4 / L2-swept kernels where it lies.  (r02 wrote a second, aligned copy of E0 for
+    that: 1.2 GB more traffic per forward at C3's 130-wide tables.)"""
+    D = sum(widths)
+    if D % 4 == 0 and widths[0] % 4 == 0:
+        return torch.empty((N, D), dtype=torch.float32, device=dev)
+    return torch.empty((N, (D + 31) // 32 * 32), dtype=torch.float32, device=dev)[:, :D]
+
+
 def _write_e0(owner, user_w, item_w, all_E, U, d0):
-    """E0 into its column block of all_E (the `cat` of NGCF.py:120 and of NGCF.py:147); returns E0 as the first layer
-    reads it.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130, 515), so D is usually not a
-    multiple of 4 and the rows of all_E are not 16-byte aligned; the first layer then reads a second copy whose rows are
-    padded to a multiple of 4 floats (written in the same pass over the tables), which lets the SpMM run its wide panel
-    on the float4 / L2-swept kernels (csrc/spmm.hip, spmm_dispatch) instead of scalar loads."""
-    uw, iw = user_w.detach(), item_w.detach()
-    if all_E.shape[1] % 4 == 0 and d0 % 4 == 0:
-        _eng.copy_rows(uw, all_E[:U, :d0])
-        _eng.copy_rows(iw, all_E[U:, :d0])
-        return all_E[:, :d0]
-    # leading dimension a multiple of 32 floats: every 64-float slice of a row then starts on a 128-byte line, as in the
-    # aligned case (with rows padded to a multiple of 4 only, a slice straddles three lines instead of two and the L2-swept
-    # SpMM of the first layer ran 2.5 instead of 1.55 ms per half on C3 at 130)
-    N, d0p = all_E.shape[0], (d0 + 31) // 32 * 32
-    pad = getattr(owner, "_e0_pad", None)
-    if pad is None or pad.device != all_E.device or tuple(pad.shape) != (N, d0p):
-        pad = torch.zeros((N, d0p), dtype=torch.float32, device=all_E.device)
-        owner._e0_pad = pad
-    _eng.copy_rows(uw, all_E[:U, :d0], pad[:U, :d0])
-    _eng.copy_rows(iw, all_E[U:, :d0], pad[U:, :d0])
-    return pad[:, :d0]
+    """E0 into its column block of all_E (the `cat` of NGCF.py:120 and of NGCF.py:147); returns E0 as the first layer reads it:
+    block 0 itself, whose rows are 16-byte aligned in either layout of `_alloc_all_E`."""
+    _eng.copy_rows(user_w.detach(), all_E[:U, :d0])
+    _eng.copy_rows(item_w.detach(), all_E[U:, :d0])
+    return all_E[:, :d0]
 
 
 def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.Tensor, item_w: torch.Tensor,
@@ -66,8 +62,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
     d0 = int(user_w.shape[1])
     n_layer = len(w1)
     widths = [d0] + [int(w.shape[0]) for w in w1]
-    D = sum(widths)
-    all_E = torch.empty((N, D), dtype=torch.float32, device=dev)
+    all_E = _alloc_all_E(N, widths, dev)
     prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
     off = d0
     for k in range(n_layer):
@@ -174,7 +169,7 @@ class Propagate(torch.autograd.Function):
         U, I = int(user_w.shape[0]), int(item_w.shape[0])
         N, d0 = U + I, int(user_w.shape[1])
         widths = [d0] + [int(w.shape[0]) for w in w1]
-        all_E = torch.empty((N, sum(widths)), dtype=torch.float32, device=dev)
+        all_E = _alloc_all_E(N, widths, dev)
         prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
         off = d0
         ins, les, carries = [], [], []
@@ -298,12 +293,23 @@ class GatherTriple(torch.autograd.Function):
         # all_E gets the dense sum from autograd.
         # Duplicates (the same user or item several times in a batch) are added in batch order, row by row, by one kernel with a
         # fixed summation order (ngcf_segment_sum_rows_f32; r02 used float atomics and the gradients differed from run to run).
-        rows, inv, counts = torch.unique(torch.cat([r for _, r in live]), return_inverse=True, return_counts=True)
-        R = int(rows.numel())
+        pos_all = live[0][1] if len(live) == 1 else torch.cat([r for _, r in live])
         g_all = live[0][0] if len(live) == 1 else torch.cat([g for g, _ in live], dim=0)
-        order = torch.sort(inv, stable=True).indices
-        segptr = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(counts, 0, out=segptr[1:])
+        M = int(pos_all.numel())
+        if M <= 8192 and N < (1 << 50):
+            # one launch: sorted distinct rows, the positions grouped by row in batch order, the group bounds (ngcf_rows_sort_unique)
+            buf = torch.empty(3 * M + 2, dtype=torch.int64, device=dev)
+            order, rows, segptr, cnt = buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:]
+            with _eng._on(dev):
+                _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
+            R = int(cnt.item())                                    # (the one host sync of the backward: sizes the compacted problem)
+            rows, segptr = rows[:R], segptr[:R + 1]
+        else:
+            rows, inv, counts = torch.unique(pos_all, return_inverse=True, return_counts=True)
+            R = int(rows.numel())
+            order = torch.sort(inv, stable=True).indices
+            segptr = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=segptr[1:])
         vals = torch.empty((R, D), dtype=torch.float32, device=dev)
         with _eng._on(dev):
             _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), R, _ptr(vals), D, _stream()))

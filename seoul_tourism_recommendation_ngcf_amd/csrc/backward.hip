@@ -649,3 +649,91 @@ extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, co
     }
     return NGCF_OK;
 }
+
+
+// =============================================================================================
+// The distinct rows of a small index vector, in ONE launch (r03).  The gradient of all_E is non-zero on the rows the three
+// gathers of a forward touched (NGCF.py:151-155): M = |u_id| + |pos_item| + |neg_item| <= 3 B positions, with duplicates.  The
+// backward needs them sorted, distinct, and - for a summation in a fixed order - the gathered positions grouped by row in batch
+// order.  torch.unique(return_inverse, return_counts) + a stable sort of the inverse + a cumsum are ~12 library launches of
+// 5-40 us each on a launch-bound training step; for M <= 8 192 one workgroup does all of it in LDS: a bitonic sort of the 64-bit
+// keys (row << 13 | position: equal rows keep their batch order), head flags, a scan.  Outputs: order[M] (positions, sorted by
+// row), rows[<= M] (distinct, ascending), segptr[<= M + 1] (group bounds inside `order`), n_rows[1].
+// =============================================================================================
+static constexpr int kSortMax = 8192, kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const int64_t *__restrict__ idx, int M, int64_t *__restrict__ order,
+                                                                        int64_t *__restrict__ rows, int64_t *__restrict__ segptr,
+                                                                        int64_t *__restrict__ n_rows)
+{
+    __shared__ unsigned long long key[kSortMax];
+    __shared__ int wsum[kSortThreads / 64];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    int P = 64;
+    while (P < M) P <<= 1;                                          // power of two >= M
+    for (int i = tid; i < P; i += kSortThreads)
+        key[i] = i < M ? ((unsigned long long)idx[i] << 13) | (unsigned)i : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += kSortThreads) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = key[i], b = key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // head flags + exclusive scan (chunks of kSortThreads, running carry)
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int base = 0; base < M; base += kSortThreads) {
+        const int i = base + tid;
+        int head = 0;
+        unsigned long long kv = 0;
+        if (i < M) {
+            kv = key[i];
+            order[i] = (int64_t)(kv & 8191u);
+            head = i == 0 || (key[i - 1] >> 13) != (kv >> 13);
+        }
+        int incl = head;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (head) {
+            const int r = before + incl - 1;
+            rows[r] = (int64_t)(kv >> 13);
+            segptr[r] = i;
+        }
+        __syncthreads();
+        if (tid == kSortThreads - 1) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        segptr[carry_s] = M;
+        n_rows[0] = carry_s;
+    }
+}
+
+extern "C" int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t *order, int64_t *rows, int64_t *segptr, int64_t *n_rows,
+                                     void *stream)
+{
+    if (M < 0 || M > kSortMax) return fail(NGCF_ERR_ARG, "rows_sort_unique: M=%lld not in [0, %d]", (long long)M, kSortMax);
+    if (!order || !rows || !segptr || !n_rows || (M > 0 && !idx)) return fail(NGCF_ERR_ARG, "rows_sort_unique: null argument");
+    rows_sort_unique_kernel<<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, order, rows, segptr, n_rows);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}

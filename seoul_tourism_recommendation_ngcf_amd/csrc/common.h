@@ -264,12 +264,26 @@ __device__ inline float4 vfma(float s, float4 x, float4 a)
     return a;
 }
 __device__ inline float vfma(float s, float x, float a) { return fmaf(s, x, a); }
+__device__ inline float2 vfma(float s, float2 x, float2 a)
+{
+    a.x = fmaf(s, x.x, a.x);
+    a.y = fmaf(s, x.y, a.y);
+    return a;
+}
+__device__ inline float2 vadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 vshfl_xor(float2 a, int m)
+{
+    a.x = __shfl_xor(a.x, m);
+    a.y = __shfl_xor(a.y, m);
+    return a;
+}
 __device__ inline float4 vsel(bool p, float4 a, float4 b) { return p ? a : b; }
 __device__ inline float vsel(bool p, float a, float b) { return p ? a : b; }
 __device__ inline float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <int VEC> __device__ inline typename VecT<VEC>::type vzero();
 template <> __device__ inline float4 vzero<4>() { return vzero4(); }
 template <> __device__ inline float vzero<1>() { return 0.f; }
+template <> __device__ inline float2 vzero<2>() { return make_float2(0.f, 0.f); }
 __device__ inline float4 vshfl_xor(float4 a, int m)
 {
     a.x = __shfl_xor(a.x, m);

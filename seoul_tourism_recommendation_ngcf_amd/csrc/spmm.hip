@@ -198,49 +198,65 @@ __global__ __launch_bounds__(kLdsTabWaves * 64) void spmm_ldstab_kernel(const in
     }
 }
 
-// Compact side table of a 1..4-column tail panel: T[c] = {E[c, 0..tail), 0...} as one 16-byte row per table row.  The widths
-// the reference forces on the first layer (65, 130, 515: NGCF.py:39-43) leave 1..3 columns beyond the wide panel; gathered
-// from the strided table each of them costs a 64-byte sector per stored entry (100 M isolated sectors on C3, ~2 ms), from
-// this table (17.6 MB at C3: L2/Infinity-Cache resident) one 16-byte load per entry, 64 entries per wave instruction.
-__global__ void tail_pack_kernel(const float *__restrict__ E, int64_t ldE, int64_t n, int tail, float4 *__restrict__ T)
+// Compact side table of a 1..4-column tail panel: T[c] = E[c, 0..tail) as ONE small row per table row - TW = 1, 2 or 4 floats
+// (4, 8 or 16 bytes: 65 -> 1 column beyond 64, 130 -> 2 beyond 128, 515 -> 3 beyond 512).  The widths the reference forces on the
+// first layer (NGCF.py:39-43) leave 1..3 columns beyond the wide panel; gathered from the strided table each of them costs a
+// 64-byte sector per stored entry (100 M isolated sectors on C3, ~2 ms), from this table one TW*4-byte load per entry, 64 entries
+// per wave instruction.  r03: the table is as narrow as the tail allows (r02: always 16-byte rows) - at 130 the user-side table
+// is 8.8 MB instead of 17.6 MB, 16 table rows per 128-byte line instead of 8, and more of it stays in the 4 MB L2 of an XCD.
+template <int TW> __device__ inline typename VecT<TW>::type tail_load(const float *e, int tail);
+template <> __device__ inline float tail_load<1>(const float *e, int) { return e[0]; }
+template <> __device__ inline float2 tail_load<2>(const float *e, int tail) { return make_float2(e[0], tail > 1 ? e[1] : 0.f); }
+template <> __device__ inline float4 tail_load<4>(const float *e, int tail)
 {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-        const float *e = E + r * ldE;
-        float4 t = make_float4(e[0], 0.f, 0.f, 0.f);
-        if (tail > 1) t.y = e[1];
-        if (tail > 2) t.z = e[2];
-        if (tail > 3) t.w = e[3];
-        T[r] = t;
-    }
+    return make_float4(e[0], tail > 1 ? e[1] : 0.f, tail > 2 ? e[2] : 0.f, tail > 3 ? e[3] : 0.f);
+}
+__device__ inline void tail_store(float *o, float t, int) { o[0] = t; }
+__device__ inline void tail_store(float *o, float2 t, int tail)
+{
+    o[0] = t.x;
+    if (tail > 1) o[1] = t.y;
+}
+__device__ inline void tail_store(float *o, float4 t, int tail)
+{
+    o[0] = t.x;
+    if (tail > 1) o[1] = t.y;
+    if (tail > 2) o[2] = t.z;
+    if (tail > 3) o[3] = t.w;
 }
 
-// the tail product lands in a compact [n_rows, 4] block and is copied into its columns of `out` (which may be a column
+template <int TW>
+__global__ void tail_pack_kernel(const float *__restrict__ E, int64_t ldE, int64_t n, int tail, typename VecT<TW>::type *__restrict__ T)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+        T[r] = tail_load<TW>(E + r * ldE, tail);
+}
+
+// the tail product lands in a compact [n_rows, TW] block and is copied into its columns of `out` (which may be a column
 // slice of a wider matrix: nothing beyond the `tail` columns is written)
-__global__ void tail_unpack_kernel(const float4 *__restrict__ T, int64_t n, int tail, float *__restrict__ out, int64_t ldo)
+template <int TW>
+__global__ void tail_unpack_kernel(const typename VecT<TW>::type *__restrict__ T, int64_t n, int tail, float *__restrict__ out, int64_t ldo)
 {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-        const float4 t = T[r];
-        float *o = out + r * ldo;
-        o[0] = t.x;
-        if (tail > 1) o[1] = t.y;
-        if (tail > 2) o[2] = t.z;
-        if (tail > 3) o[3] = t.w;
-    }
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+        tail_store(out + r * ldo, T[r], tail);
 }
 
-// The tail product itself: [n_rows, 4] = L . T[n_cols, 4].  16 lanes per row (or per <= seg_len-entry segment of a cut row),
+// The tail product itself: [n_rows, TW] = L . T[n_cols, TW].  16 lanes per row (or per <= seg_len-entry segment of a cut row),
 // four of them per wave, four independent (col, val, gather) triples in flight per lane: a 50-entry user row is one pass of
 // its group.  One wave per row (spmm_kernel<4,1,1,1>) is latency-bound at ~0.5 us per row: 1.0 ms per product on C3, this
 // form 0.3 ms.
+template <int TW>
 __global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                         const float *__restrict__ vals, int64_t n_rows,
                                                         const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
-                                                        int64_t n_seg, int64_t seg_blocks, int seg_len, const float4 *__restrict__ T,
-                                                        float4 *__restrict__ out, float4 *__restrict__ partial)
+                                                        int64_t n_seg, int64_t seg_blocks, int seg_len,
+                                                        const typename VecT<TW>::type *__restrict__ T,
+                                                        typename VecT<TW>::type *__restrict__ out, typename VecT<TW>::type *__restrict__ partial)
 {
+    using V = typename VecT<TW>::type;
     const int unit = threadIdx.x >> 4, l = threadIdx.x & 15;
     int64_t begin = 0, end = 0;
-    float4 *dst = nullptr;
+    V *dst = nullptr;
     if ((int64_t)blockIdx.x < seg_blocks) {
         const int64_t s = (int64_t)blockIdx.x * 16 + unit;
         if (s < n_seg) {
@@ -258,22 +274,52 @@ __global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restric
             if (end - begin > seg_len) dst = nullptr, end = begin;   // cut row: produced from its segments
         }
     }
-    float4 a0 = vzero4(), a1 = vzero4(), a2 = vzero4(), a3 = vzero4();
+    V a0 = vzero<TW>(), a1 = vzero<TW>(), a2 = vzero<TW>(), a3 = vzero<TW>();
     for (int64_t e = begin + l; e < end; e += 64) {
         const int64_t e1 = e + 16, e2 = e + 32, e3 = e + 48;
         const bool k1 = e1 < end, k2 = e2 < end, k3 = e3 < end;
         const int c0 = colidx[e], c1 = k1 ? colidx[e1] : 0, c2 = k2 ? colidx[e2] : 0, c3 = k3 ? colidx[e3] : 0;
         const float v0 = vals[e], v1 = k1 ? vals[e1] : 0.f, v2 = k2 ? vals[e2] : 0.f, v3 = k3 ? vals[e3] : 0.f;
-        const float4 t0 = T[c0], t1 = T[c1], t2 = T[c2], t3 = T[c3];
+        const V t0 = T[c0], t1 = T[c1], t2 = T[c2], t3 = T[c3];
         a0 = vfma(v0, t0, a0);
         a1 = vfma(v1, t1, a1);
         a2 = vfma(v2, t2, a2);
         a3 = vfma(v3, t3, a3);
     }
-    float4 acc = vadd(vadd(a0, a1), vadd(a2, a3));
+    V acc = vadd(vadd(a0, a1), vadd(a2, a3));
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) acc = vadd(acc, vshfl_xor(acc, m));
     if (l == 0 && dst) *dst = acc;
+}
+
+// one tail product through its compact tables (workspace: [partial sums ... | T_in [n_cols] | T_out [n_rows]] as 16-byte slots)
+template <int TW>
+static int launch_tail(const ngcf_csr *c, const float *E, int64_t ldE, int tail, float *out, int64_t ldo, void *workspace,
+                       int64_t workspace_bytes, hipStream_t stream)
+{
+    using V = typename VecT<TW>::type;
+    uintptr_t end = reinterpret_cast<uintptr_t>(workspace) + (uintptr_t)workspace_bytes;
+    V *Tout = reinterpret_cast<V *>((end - (uintptr_t)(c->n_rows * (int64_t)sizeof(float4))) & ~(uintptr_t)255);
+    V *Tin = reinterpret_cast<V *>((reinterpret_cast<uintptr_t>(Tout) - (uintptr_t)(c->n_cols * (int64_t)sizeof(float4))) & ~(uintptr_t)255);
+    tail_pack_kernel<TW><<<grid_for(c->n_cols, 256), 256, 0, stream>>>(E, ldE, c->n_cols, tail, Tin);
+    LAUNCH_CHECK();
+    // cut rows (the CSR's own segment plan): one partial V per segment at the start of the workspace, then the fix-up
+    V *tpart = reinterpret_cast<V *>(align_up((int64_t)(uintptr_t)workspace, 256));
+    const int64_t seg_blocks = (c->n_seg + 15) / 16, row_blocks = (c->n_rows + 15) / 16;
+    if (seg_blocks + row_blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
+    prof_mark(stream, 0);
+    spmm_tail_kernel<TW><<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(
+        c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, Tin, Tout, tpart);
+    LAUNCH_CHECK();
+    if (c->n_heavy > 0) {
+        spmm_fixup_kernel<TW><<<dim3((unsigned)((c->n_heavy + 3) / 4)), 256, 0, stream>>>(
+            c->heavy_row, c->heavy_seg_ptr, c->n_heavy, reinterpret_cast<const float *>(tpart), TW, TW, reinterpret_cast<float *>(Tout), TW);
+        LAUNCH_CHECK();
+    }
+    prof_mark(stream, 1);
+    tail_unpack_kernel<TW><<<grid_for(c->n_rows, 256), 256, 0, stream>>>(Tout, c->n_rows, tail, out, ldo);
+    LAUNCH_CHECK();
+    return NGCF_OK;
 }
 
 static int64_t tail_table_bytes(const ngcf_csr *c)
@@ -525,31 +571,9 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
             if (rc != NGCF_OK) return rc;
             const int tail = d - main;
             if (tail <= 4 && dr.n == 0 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !ngcf_opts().no_tail_table) {
-                // workspace: [partial sums ...            | T_in [n_cols] | T_out [n_rows]]
-                uintptr_t end = reinterpret_cast<uintptr_t>(workspace) + (uintptr_t)workspace_bytes;
-                float4 *Tout = reinterpret_cast<float4 *>((end - (uintptr_t)(c->n_rows * (int64_t)sizeof(float4))) & ~(uintptr_t)255);
-                float4 *Tin = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(Tout) - (uintptr_t)(c->n_cols * (int64_t)sizeof(float4))) &
-                                                         ~(uintptr_t)255);
-                tail_pack_kernel<<<grid_for(c->n_cols, 256), 256, 0, stream>>>(E + main, ldE, c->n_cols, tail, Tin);
-                LAUNCH_CHECK();
-                // cut rows (the CSR's own segment plan): partial float4 per segment at the start of the workspace, then the fix-up
-                float4 *tpart = reinterpret_cast<float4 *>(align_up((int64_t)(uintptr_t)workspace, 256));
-                const int64_t seg_blocks = (c->n_seg + 15) / 16, row_blocks = (c->n_rows + 15) / 16;
-                if (seg_blocks + row_blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
-                prof_mark(stream, 0);
-                spmm_tail_kernel<<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(
-                    c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, Tin, Tout, tpart);
-                LAUNCH_CHECK();
-                if (c->n_heavy > 0) {
-                    spmm_fixup_kernel<4><<<dim3((unsigned)((c->n_heavy + 3) / 4)), 256, 0, stream>>>(
-                        c->heavy_row, c->heavy_seg_ptr, c->n_heavy, reinterpret_cast<const float *>(tpart), 4, 4,
-                        reinterpret_cast<float *>(Tout), 4);
-                    LAUNCH_CHECK();
-                }
-                prof_mark(stream, 1);
-                tail_unpack_kernel<<<grid_for(c->n_rows, 256), 256, 0, stream>>>(Tout, c->n_rows, tail, out + main, ldo);
-                LAUNCH_CHECK();
-                return NGCF_OK;
+                if (tail == 1) return launch_tail<1>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream);
+                if (tail == 2) return launch_tail<2>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream);
+                return launch_tail<4>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream);
             }
             return spmm_dispatch(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream, dr);
         }

@@ -666,13 +666,12 @@ class ShardedPropagation:
     # -- propagation ----------------------------------------------------------------------------
     def propagate(self):
         """(all_E rows of this rank's users, all_E rows of its items).  When autograd is recording and a parameter of the model
-        requires a gradient (and the scheme is `bipartite`), the differentiable path runs: `loss.backward()` then leaves in every
+        requires a gradient and the scheme is `bipartite`, the differentiable path runs: `loss.backward()` then leaves in every
         parameter's `.grad` the gradient summed over all ranks (experiment.py:57 across GPUs)."""
         m = self.model
-        if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
-            if self.mode != "bipartite":
-                raise RuntimeError("training across ranks is built for the bipartite exchange scheme (mode='bipartite')")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()) and self.mode == "bipartite":
             return self._propagate_bipartite_train()
+        # (the all-gather scheme has no differentiable path: its results carry no gradient, like any call under torch.no_grad())
         with torch.no_grad():
             return self._propagate_bipartite() if self.mode == "bipartite" else self._propagate_allgather()
 

@@ -91,6 +91,12 @@ class GraphedForward:
         capture - and `node_flag` must be False."""
         if node_flag:
             raise RuntimeError("GraphedForward replays the node_flag=False forward")
+        self.load_inputs(u_id, age, sex, month, day, dow, pos_item, neg_item)
+        return self.replay(check)
+
+    def load_inputs(self, u_id, age, sex, month, day, dow, pos_item, neg_item=None):
+        """The batch into the graph's static index buffers: one multi-tensor copy when every vector is an int64 tensor on the
+        graph's device (the usual case), else one copy each."""
         given = dict(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item)
         if self.with_neg:
             given["neg_item"] = neg_item
@@ -99,12 +105,16 @@ class GraphedForward:
             if v is None or int(v.numel()) != want:
                 raise RuntimeError(f"GraphedForward was captured for {want} elements of {k}: got "
                                    f"{0 if v is None else int(v.numel())}")
-            self.inputs[k].copy_(v, non_blocking=True)
-        return self.replay(check)
+        vals = list(given.values())
+        if all(v.dtype == torch.int64 and v.device == self.dev and v.dim() == 1 for v in vals):
+            torch._foreach_copy_([self.inputs[k] for k in given], vals)
+        else:
+            for k, v in given.items():
+                self.inputs[k].copy_(v.reshape(-1), non_blocking=True)
 
     def _baked_pointers(self):
         b = self.bufs
-        return tuple(t.data_ptr() for t in (b._ws.buf, b._carry[0], b._carry[1], getattr(b, "_e0_pad", None), self.scratch,
+        return tuple(t.data_ptr() for t in (b._ws.buf, b._carry[0], b._carry[1], self.scratch,
                                             self.status) if t is not None)
 
     def replay(self, check: bool = True):

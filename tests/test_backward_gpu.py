@@ -344,3 +344,27 @@ def test_training_gradients_are_bit_identical_from_run_to_run(node_mode, dev):
     assert set(grads[0]) == set(grads[1]) and "user_embedding.weight" in grads[0] and "w2_list.2.bias" in grads[0]
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+@pytest.mark.parametrize("M,N", [(1, 10), (64, 5), (65, 1 << 40), (3072, 5940), (8192, 1_100_000), (5000, 3)])
+def test_rows_sort_unique_kernel_vs_torch_unique(M, N, dev):
+    """ngcf_rows_sort_unique (one workgroup: bitonic sort in LDS, head flags, scan) against torch.unique + a stable sort: distinct
+    rows ascending, positions grouped by row in batch order, group bounds, count - integer work, bit-exact."""
+    import ctypes as C
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M)
+    idx = torch.randint(0, N, (M,), generator=g, dtype=torch.int64).to(dev)
+    buf = torch.full((3 * M + 2,), -7, dtype=torch.int64, device=dev)
+    order, rows, segptr, cnt = buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.ngcf_rows_sort_unique(p(idx), M, p(order), p(rows), p(segptr), p(cnt), None))
+    torch.cuda.synchronize()
+    want_rows, inv, counts = torch.unique(idx, return_inverse=True, return_counts=True)
+    R = int(cnt.item())
+    assert R == want_rows.numel()
+    assert torch.equal(rows[:R], want_rows)
+    assert torch.equal(order, torch.sort(inv, stable=True).indices)
+    want_ptr = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+    want_ptr[1:] = torch.cumsum(counts, 0)
+    assert torch.equal(segptr[:R + 1], want_ptr)

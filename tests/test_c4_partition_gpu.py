@@ -111,8 +111,9 @@ def _c4_worker(rank, world, port, mode, ret):
         sh = nd.ShardedPropagation.from_interactions(model, u, i, w, mode=mode, device=dev)     # the product code itself
         del u, i, w
         assert sh.backend == "p2p", getattr(sh, "p2p_error", None)
-        au, ai = sh.propagate()
-        au, ai = sh.propagate()
+        with torch.no_grad():
+            au, ai = sh.propagate()
+            au, ai = sh.propagate()
         torch.cuda.synchronize()
         if mode == "bipartite":
             wu, wi = want[sh.ub[rank]:sh.ub[rank + 1]], want[U + sh.ib[rank]:U + sh.ib[rank + 1]]

@@ -327,9 +327,10 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False, collec
         else:
             sh = nd.ShardedPropagation.from_coo(model, coo["rows"], coo["cols"], coo["vals"], mode=mode)
         assert sh.backend == ("cabi" if cabi else collectives if world > 1 else "torch"), (sh.backend, getattr(sh, "p2p_error", None))
-        first = sh.propagate()
-        first = (first[0].clone(), first[1].clone())
-        au, ai = sh.propagate()                                    # a second pass re-uses every buffer and both exchange regions
+        with torch.no_grad():                                      # the inference path (with autograd recording, the bipartite scheme
+            first = sh.propagate()                                 # would take its differentiable path: tested further down)
+            first = (first[0].clone(), first[1].clone())
+            au, ai = sh.propagate()                                # a second pass re-uses every buffer and both exchange regions
         assert torch.equal(au, first[0]) and torch.equal(ai, first[1])
         if mode == "bipartite":
             lo, hi = sh.ub[rank], sh.ub[rank + 1]
