@@ -61,7 +61,6 @@ struct NgcfOptions {
     int no_tail_table = 0;         // NGCF_NO_TAIL_TABLE: tail columns gathered out of the strided table
     int no_pad_product = 0;        // NGCF_NO_PAD_PRODUCT: small matrices: do not multiply the padding columns along
     int64_t fork_min = 200000000;  // NGCF_FORK_MIN: entry-columns from which the halves are forked under capture
-    int tail_overlap = 1;          // NGCF_TAIL_OVERLAP: the tail product of an odd width on a second stream beside the main panel
     // dense.hip
     int dense_direct = 1;          // NGCF_DENSE_DIRECT: 0 never, 1 up to 8 192 rows, 2 at any row count
     int dense_resident = 1;        // NGCF_DENSE_RESIDENT: 0 keeps the staged kernel

@@ -34,7 +34,6 @@ const OptField kOptFields[] = {
     {"no_tail_table", &NgcfOptions::no_tail_table, nullptr},
     {"no_pad_product", &NgcfOptions::no_pad_product, nullptr},
     {"fork_min", nullptr, &NgcfOptions::fork_min},
-    {"tail_overlap", &NgcfOptions::tail_overlap, nullptr},
     {"dense_direct", &NgcfOptions::dense_direct, nullptr},
     {"dense_resident", &NgcfOptions::dense_resident, nullptr},
     {"dense_small_tiles", &NgcfOptions::dense_small_tiles, nullptr},
