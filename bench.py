@@ -338,6 +338,7 @@ def main():
     import torch.distributed as dist
     if world > 1:
         import datetime
+        os.environ.setdefault("NGCF_P2P_TIMEOUT_MS", "30000")  # a dead peer must not hold the others for the default minute per wait
         to = datetime.timedelta(minutes=5)             # a rank that dies must not leave the others waiting for the default half hour
         if share:
             dist.init_process_group("gloo", timeout=to)
@@ -456,6 +457,26 @@ def main():
 
     torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
     dt, loss, n_launch, spmm_ms = timed(step, True)
+    transport_check = None
+    if world > 1 and sh.backend == "p2p" and not args.no_secondary:
+        # The same scheme over torch.distributed collectives (RCCL), timed the same way: a cross-check of the p2p transport's
+        # RESULT (the two losses must agree) and its price tag.  `value` is the p2p run unless the losses disagree - then the
+        # RCCL run is the headline and the line says so.
+        os.environ["NGCF_DIST_COLLECTIVES"] = "torch"
+        sh_t = ngcf_dist.ShardedPropagation.from_interactions(model, *inter, mode=args.exchange, device=dev)
+        os.environ.pop("NGCF_DIST_COLLECTIVES")
+
+        def step_t():
+            sh_t.propagate()
+            u, p, n = sh_t.gather(u_id, pos, neg)
+            return crit(u, p, n)
+        dt_t, loss_t, n_launch_t, spmm_ms_t = timed(step_t, True)
+        agree = abs(float(loss) - float(loss_t)) <= 1e-5 * abs(float(loss_t))
+        transport_check = {"p2p": {"ms_per_step": dt / args.steps * 1e3, "loss": float(loss)},
+                           "torch_rccl": {"ms_per_step": dt_t / args.steps * 1e3, "loss": float(loss_t)}, "losses_agree": bool(agree)}
+        if not agree:
+            dt, loss, n_launch, spmm_ms, sh = dt_t, loss_t, n_launch_t, spmm_ms_t, sh_t
+            spmm_shapes, local_nnz = sh.spmm_shapes(), sh.local_nnz
 
     n_layer = len(layers)
     edges_per_step = n_layer * nnz                            # whole job, all ranks
@@ -592,6 +613,8 @@ def main():
                         "note": "explanatory, not the headline: roofline.frac stays SURVEY 8d model A"},
         "loss": float(loss),
     }
+    if transport_check:
+        out["transport_check"] = transport_check
     if secondary:
         out["secondary"] = secondary
     if seoul:

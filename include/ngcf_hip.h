@@ -43,7 +43,7 @@ const char *ngcf_last_error(void);
 const char *ngcf_target_arch(void);
 /* ABI version of this header.  ngcf_version() returns the value the library was built with; the Python mirror refuses to bind
  * a library whose version differs (a stale .so would otherwise receive shifted arguments). */
-#define NGCF_ABI_VERSION 3
+#define NGCF_ABI_VERSION 4
 int ngcf_version(void);
 
 /* Tunables of the kernel dispatch (thresholds, lab switches).  The library reads its NGCF_* environment variables ONCE, in
@@ -265,7 +265,10 @@ int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp
  * of all_E in a fixed order: out[r, :] = sum of g[order[j], :] for j in [segptr[r], segptr[r+1]), in that order (`order`: the
  * gathered positions sorted by row, stable - duplicates add up in batch order; int64 device arrays).  No atomics. */
 int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr, int64_t n_seg,
-                              float *out, int64_t ldo, void *stream);
+                              const int64_t *dst_rows, const int64_t *n_seg_dev, float *out, int64_t ldo, void *stream);
+/* (dst_rows != NULL: the sum of segment r goes to row dst_rows[r] of `out` - the scatter into a dense, zero-filled gradient of
+ * all_E; n_seg_dev != NULL: only the first *n_seg_dev segments exist (the count ngcf_rows_sort_unique left on the device: no
+ * host round trip between the two launches), n_seg is then an upper bound that sizes the grid) */
 /* The distinct rows among M <= 8 192 gathered positions, in one launch: idx int64[M] (rows of all_E, each < 2^50) ->
  * order int64[M] (the positions 0..M-1 sorted by row, equal rows in batch order), rows int64[<= M] (distinct, ascending),
  * segptr int64[<= M + 1] (group bounds inside `order`), n_rows int64[1].  All device arrays sized for M (segptr M + 1).
@@ -295,16 +298,15 @@ int64_t ngcf_layer_bwd_input_workspace_bytes(int d_out);
 int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_rows, int d_out, const float *W1, const float *W2,
                              int d_in, const float *LE, int64_t ldLE, const float *E, int64_t ldE, float *dLE, int64_t ldd,
                              float *dE, int64_t lde, void *workspace, int64_t workspace_bytes, void *stream);
-/* weight gradients of one layer on the fp32 matrix cores: gW [d_out, 2 d_in] row-major,
- * gW[:, :d_in] = dM^T . (LE + E) (W1, NGCF.py:131-133), gW[:, d_in:] = dM^T . (LE * E) (W2, NGCF.py:135-136);
- * d_in, d_out <= 128 per call (the host tiles wider layers over column blocks of dM, LE and E).  Fixed
- * summation order (per-workgroup partials in the workspace, added in workgroup order).
- * gb (may be NULL): [d_out] column sums of dM from the same pass - the bias gradient of W2's bias, and half that of W1's
- * (b1 enters the layer twice, NGCF.py:131,133). */
+/* weight gradients of one layer on the fp32 matrix cores: gW1 [d_out, d_in] = dM^T . (LE + E) (the gradient of W1,
+ * NGCF.py:131-133), gW2 [d_out, d_in] = dM^T . (LE * E) (W2, NGCF.py:135-136), each row-major with its own leading dimension
+ * (so a caller tiling a wide layer passes sub-blocks of the full gradients); d_in, d_out <= 128 per call.  Fixed summation
+ * order (per-workgroup partials in the workspace, added in workgroup order).  gb2 / gb1 (may be NULL): [d_out] column sums of dM
+ * from the same pass and twice that - the gradients of W2's and W1's bias (b1 enters the layer twice, NGCF.py:131,133). */
 int64_t ngcf_bwd_weight_workspace_bytes(void);
 int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E, int64_t ldE,
-                              int64_t n_rows, int d_in, int d_out, float *gW, float *gb, void *workspace,
-                              int64_t workspace_bytes, void *stream);
+                              int64_t n_rows, int d_in, int d_out, float *gW1, int64_t ld1, float *gW2, int64_t ld2,
+                              float *gb1, float *gb2, void *workspace, int64_t workspace_bytes, void *stream);
 /* out[r, 0:d] += add[r, 0:d] */
 int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream);
 

@@ -19,6 +19,7 @@ from .engine import _ptr, _row_major_ld, _stream
 
 
 SPARSE_LAST_LAYER = True        # row-sparse backward of the last layer (Propagate.backward); False: always the dense path
+DENSE_GRAD_MAX_BYTES = 32 << 20  # all_E up to this size: GatherTriple hands over a dense gradient (no host sync in the backward)
 sparse_last_layer_calls = 0     # how often the row-sparse path ran (tests)
 
 
@@ -107,31 +108,29 @@ def _bwd_pre(dN, dC, Cc, leaky, drop_p, seed, mask=None, row_ids=None):
 
 
 def _bwd_weight(dM, LE, E, ws):
-    """gW [d_out, 2 d_in] = dM^T . [LE+E | LE*E] on the fp32 matrix cores and gb [d_out] = column sums of dM (the bias
-    gradient) from the same pass over dM (ngcf_layer_bwd_weight_f32), in blocks of at most 128 output rows x 128 input
-    columns (one kernel call each)."""
+    """(gW1, gb1, gW2, gb2): gW1 = dM^T . (LE + E), gW2 = dM^T . (LE * E) on the fp32 matrix cores, gb2 = column sums of dM and
+    gb1 = twice that (b1 enters the layer twice) from the same pass over dM (ngcf_layer_bwd_weight_f32), written straight into the
+    four gradient tensors; blocks of at most 128 output rows x 128 input columns (one kernel call each)."""
     lib = _lib.load()
     n_rows, d_out = dM.shape
     d_in = int(LE.shape[1])
-    gW = torch.empty((d_out, 2 * d_in), dtype=torch.float32, device=dM.device)
-    gb = torch.empty((d_out,), dtype=torch.float32, device=dM.device)
-    nb = int(lib.ngcf_bwd_weight_workspace_bytes())
-    w = ws.get(nb, dM.device)
+    gW1 = torch.empty((d_out, d_in), dtype=torch.float32, device=dM.device)
+    gW2 = torch.empty((d_out, d_in), dtype=torch.float32, device=dM.device)
+    gb1 = torch.empty((d_out,), dtype=torch.float32, device=dM.device)
+    gb2 = torch.empty((d_out,), dtype=torch.float32, device=dM.device)
+    w = ws.get(int(lib.ngcf_bwd_weight_workspace_bytes()), dM.device)
     with _eng._on(dM.device):
         for o0 in range(0, d_out, 128):
             o1 = min(d_out, o0 + 128)
             for c0 in range(0, d_in, 128):
                 c1 = min(d_in, c0 + 128)
-                whole = o0 == 0 and o1 == d_out and c0 == 0 and c1 == d_in
-                blk = gW if whole else torch.empty((o1 - o0, 2 * (c1 - c0)), dtype=torch.float32, device=dM.device)
                 a, b, c = dM[:, o0:o1], LE[:, c0:c1], E[:, c0:c1]
                 _lib.check(lib.ngcf_layer_bwd_weight_f32(_ptr(a), _row_major_ld(a, "dM"), _ptr(b), _row_major_ld(b, "LE"),
-                                                         _ptr(c), _row_major_ld(c, "E"), n_rows, c1 - c0, o1 - o0, _ptr(blk),
-                                                         _ptr(gb[o0:o1]) if c0 == 0 else None, _ptr(w), w.numel(), _stream()))
-                if not whole:
-                    gW[o0:o1, c0:c1] = blk[:, :c1 - c0]
-                    gW[o0:o1, d_in + c0:d_in + c1] = blk[:, c1 - c0:]
-    return gW, gb
+                                                         _ptr(c), _row_major_ld(c, "E"), n_rows, c1 - c0, o1 - o0,
+                                                         _ptr(gW1[o0:o1, c0:c1]), d_in, _ptr(gW2[o0:o1, c0:c1]), d_in,
+                                                         _ptr(gb1[o0:o1]) if c0 == 0 else None, _ptr(gb2[o0:o1]) if c0 == 0 else None,
+                                                         _ptr(w), w.numel(), _stream()))
+    return gW1, gb1, gW2, gb2
 
 
 def _bwd_input(dM, w1, w2, LE, E, ws):
@@ -231,9 +230,7 @@ class Propagate(torch.autograd.Function):
                 dM = _bwd_pre(gv[:, offs[k]:offs[k] + d_out], None, C_k[rows], _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k],
                               None if mask_k is None else mask_k[rows], rows)
                 LE_c, E_c = LE_k[rows], E_k[rows]
-                gW, gb = _bwd_weight(dM, LE_c, E_c, ws)
-                gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
-                gb1[k], gb2[k] = 2.0 * gb, gb
+                gw1[k], gb1[k], gw2[k], gb2[k] = _bwd_weight(dM, LE_c, E_c, ws)
                 dLE_c, dE_c = _bwd_input(dM, w1[k], w2[k], LE_c, E_c, ws)
                 N = int(all_E.shape[0])
                 dE = _padded_rows(N, d_in, all_E.device)
@@ -249,9 +246,7 @@ class Propagate(torch.autograd.Function):
                                     None if mask_k is None else mask_k[rows], rows)
             else:
                 dM = _bwd_pre(g_all[:, offs[k]:offs[k] + d_out], dC, C_k, _eng.LEAKY_SLOPE, ctx.drop[k], ctx.seeds[k], mask_k)
-            gW, gb = _bwd_weight(dM, LE_k, E_k, ws)                              # MFMA kernel, operand formed on the fly; bias too
-            gw1[k], gw2[k] = gW[:, :d_in].contiguous(), gW[:, d_in:].contiguous()
-            gb1[k], gb2[k] = 2.0 * gb, gb                                        # b1 enters twice (NGCF.py:131,133)
+            gw1[k], gb1[k], gw2[k], gb2[k] = _bwd_weight(dM, LE_k, E_k, ws)      # MFMA kernel, operand formed on the fly; biases too
             dLE, dE = _bwd_input(dM, w1[k], w2[k], LE_k, E_k, ws)                 # one MFMA kernel at any width, dS/dP never stored
             del dM
             ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], True)
@@ -296,6 +291,19 @@ class GatherTriple(torch.autograd.Function):
         pos_all = live[0][1] if len(live) == 1 else torch.cat([r for _, r in live])
         g_all = live[0][0] if len(live) == 1 else torch.cat([g for g, _ in live], dim=0)
         M = int(pos_all.numel())
+        if M <= 8192 and N * D * 4 <= DENSE_GRAD_MAX_BYTES:
+            # A SMALL graph (the Seoul data: all_E is 6 MB): a dense gradient costs nothing and the whole backward then runs
+            # without a single host sync - the distinct rows, their count and the group bounds stay on the device between the
+            # sort and the scatter of the segment sums into a zero-filled [N, D] matrix, and Propagate.backward takes its dense
+            # path (no compaction gathers, no index_put: ~15 launches fewer per step than the row-sparse path)
+            buf = torch.empty(3 * M + 2, dtype=torch.int64, device=dev)
+            order, rows, segptr, cnt = buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:]
+            G = torch.zeros((N, D), dtype=torch.float32, device=dev)
+            with _eng._on(dev):
+                _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
+                _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), M, _ptr(rows), _ptr(cnt), _ptr(G), D,
+                                                         _stream()))
+            return (G, None, None, None, None, None)
         if M <= 8192 and N < (1 << 50):
             # one launch: sorted distinct rows, the positions grouped by row in batch order, the group bounds (ngcf_rows_sort_unique)
             buf = torch.empty(3 * M + 2, dtype=torch.int64, device=dev)
@@ -312,7 +320,7 @@ class GatherTriple(torch.autograd.Function):
             torch.cumsum(counts, 0, out=segptr[1:])
         vals = torch.empty((R, D), dtype=torch.float32, device=dev)
         with _eng._on(dev):
-            _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), R, _ptr(vals), D, _stream()))
+            _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), R, None, None, _ptr(vals), D, _stream()))
         G = torch.sparse_coo_tensor(rows[None], vals, (N, D), is_coalesced=True)
         return (G, None, None, None, None, None)
 

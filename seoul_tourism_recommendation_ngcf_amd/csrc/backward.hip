@@ -71,11 +71,13 @@ extern "C" int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p,
 // the same bits.  One wave per output row.
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ g, int64_t ldg, int d,
                                                                const int64_t *__restrict__ order, const int64_t *__restrict__ segptr,
-                                                               int64_t n_seg, float *__restrict__ out, int64_t ldo)
+                                                               int64_t n_seg, const int64_t *__restrict__ dst_rows,
+                                                               const int64_t *__restrict__ n_seg_dev, float *__restrict__ out, int64_t ldo)
 {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_seg) return;
+    int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_seg || (n_seg_dev && r >= *n_seg_dev)) return;       // n_seg_dev: the number of segments lives on the device
     const int64_t j0 = segptr[r], j1 = segptr[r + 1];
+    if (dst_rows) r = dst_rows[r];                                  // scatter form: segment r is row dst_rows[r] of a larger matrix
     // four chains over the segment (positions j0 + 4 i + q), combined as (s0 + s1) + (s2 + s3): a fixed order whose loads do not
     // wait for each other (a popular item is gathered 20 times in a batch of 1 024 on the Seoul graph's 100 items)
     for (int c = threadIdx.x & 63; c < d; c += 64) {
@@ -94,13 +96,14 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__re
 }
 
 extern "C" int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr,
-                                         int64_t n_seg, float *out, int64_t ldo, void *stream_)
+                                         int64_t n_seg, const int64_t *dst_rows, const int64_t *n_seg_dev, float *out, int64_t ldo,
+                                         void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_seg == 0) return NGCF_OK;
     if (!g || !order || !segptr || !out || d <= 0 || ldg < d || ldo < d || n_seg < 0) return fail(NGCF_ERR_ARG, "segment_sum_rows: bad argument");
     if ((n_seg + 3) / 4 >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "segment_sum_rows: too many rows");
-    segment_sum_rows_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), 256, 0, stream>>>(g, ldg, d, order, segptr, n_seg, out, ldo);
+    segment_sum_rows_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), 256, 0, stream>>>(g, ldg, d, order, segptr, n_seg, dst_rows, n_seg_dev, out, ldo);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -297,15 +300,17 @@ __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict
 }
 
 __global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ partial_bias, int n_wg, int d_in,
-                                         int d_out, int P, float *__restrict__ gW, float *__restrict__ gb)
+                                         int d_out, int P, float *__restrict__ gW1, int64_t ld1, float *__restrict__ gW2, int64_t ld2,
+                                         float *__restrict__ gb1, float *__restrict__ gb2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d_out * 2 * d_in) {
         const int o = i - d_out * 2 * d_in;
-        if (gb && o < d_out) {
+        if ((gb1 || gb2) && o < d_out) {
             float s = 0.f;
             for (int w = 0; w < n_wg; ++w) s += partial_bias[(int64_t)w * kBwM + o];
-            gb[o] = s;
+            if (gb2) gb2[o] = s;
+            if (gb1) gb1[o] = 2.0f * s;          // b1 enters the layer twice (NGCF.py:131,133)
         }
         return;
     }
@@ -323,7 +328,9 @@ __global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, cons
         s3 += p[(w + 3) * step];
     }
     for (; w < n_wg; ++w) s0 += p[w * step];
-    gW[i] = (s0 + s1) + (s2 + s3);
+    const float r = (s0 + s1) + (s2 + s3);
+    if (c < d_in) gW1[(int64_t)o * ld1 + c] = r;
+    else gW2[(int64_t)o * ld2 + (c - d_in)] = r;
 }
 
 extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void)
@@ -332,11 +339,12 @@ extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void)
 }
 
 extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const float *LE, int64_t ldLE, const float *E,
-                                         int64_t ldE, int64_t n_rows, int d_in, int d_out, float *gW, float *gb, void *workspace,
-                                         int64_t workspace_bytes, void *stream_)
+                                         int64_t ldE, int64_t n_rows, int d_in, int d_out, float *gW1, int64_t ld1, float *gW2,
+                                         int64_t ld2, float *gb1, float *gb2, void *workspace, int64_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!gW || (n_rows > 0 && (!dM || !LE || !E))) return fail(NGCF_ERR_ARG, "layer_bwd_weight: null argument");
+    if (!gW1 || !gW2 || ld1 < d_in || ld2 < d_in || (n_rows > 0 && (!dM || !LE || !E)))
+        return fail(NGCF_ERR_ARG, "layer_bwd_weight: null argument or leading dimension too small");
     if (n_rows < 0 || d_in < 1 || d_out < 1 || d_in > 128 || d_out > 128)
         return fail(NGCF_ERR_ARG, "layer_bwd_weight: widths d_in=%d d_out=%d not in 1..128", d_in, d_out);
     if (ldM < d_out || ldLE < d_in || ldE < d_in) return fail(NGCF_ERR_ARG, "layer_bwd_weight: leading dimension too small");
@@ -357,8 +365,8 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
     else
         bwd_weight_kernel<false><<<n_wg, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     LAUNCH_CHECK();
-    const int total = d_out * 2 * d_in + (gb ? d_out : 0);
-    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, partial_bias, n_wg, d_in, d_out, P, gW, gb);
+    const int total = d_out * 2 * d_in + ((gb1 || gb2) ? d_out : 0);
+    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, partial_bias, n_wg, d_in, d_out, P, gW1, ld1, gW2, ld2, gb1, gb2);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

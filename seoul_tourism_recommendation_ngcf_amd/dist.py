@@ -235,6 +235,8 @@ class _CabiAllGather:
 # ------------------------------------------------------------------------------------------------
 def _reduce_scatter_rows(full: torch.Tensor, group) -> torch.Tensor:
     """own[m, d] = sum over ranks of full[rank*m:(rank+1)*m] (gloo has no reduce-scatter: all-reduce + own rows)."""
+    if isinstance(group, P2PCollectives):
+        return group.reduce_scatter(full)
     W, r = dist.get_world_size(group), dist.get_rank(group)
     m = full.shape[0] // W
     if dist.get_backend(group) == "nccl":
@@ -246,35 +248,39 @@ def _reduce_scatter_rows(full: torch.Tensor, group) -> torch.Tensor:
     return tmp[r * m:(r + 1) * m].clone()
 
 
+def _all_gather_rows(send: torch.Tensor, comm) -> torch.Tensor:
+    """`comm`: a process group (or None = the default group) for torch.distributed, or a `P2PCollectives` for the CU-free exchange."""
+    if isinstance(comm, P2PCollectives):
+        return comm.all_gather(send)
+    full = torch.empty((send.shape[0] * dist.get_world_size(comm), send.shape[1]), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(full, send.contiguous(), group=comm)
+    return full
+
+
 class AllGatherRows(torch.autograd.Function):
     """full[W*m, d] = every rank's send[m, d], rank-major.  Adjoint: reduce-scatter of the gradient (every rank used every row)."""
 
     @staticmethod
-    def forward(ctx, send, group):
-        ctx.group = group
-        full = torch.empty((send.shape[0] * dist.get_world_size(group), send.shape[1]), dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(full, send.contiguous(), group=group)
-        return full
+    def forward(ctx, send, comm):
+        ctx.comm = comm
+        return _all_gather_rows(send, comm)
 
     @staticmethod
     def backward(ctx, g):
-        return _reduce_scatter_rows(g, ctx.group), None
+        return _reduce_scatter_rows(g, ctx.comm), None
 
 
 class ReduceScatterRows(torch.autograd.Function):
     """own[m, d] = sum over ranks of their full[rank*m:(rank+1)*m].  Adjoint: all-gather of the gradient."""
 
     @staticmethod
-    def forward(ctx, full, group):
-        ctx.group = group
-        return _reduce_scatter_rows(full, group)
+    def forward(ctx, full, comm):
+        ctx.comm = comm
+        return _reduce_scatter_rows(full, comm)
 
     @staticmethod
     def backward(ctx, g):
-        W = dist.get_world_size(ctx.group)
-        out = torch.empty((g.shape[0] * W, g.shape[1]), dtype=g.dtype, device=g.device)
-        dist.all_gather_into_tensor(out, g.contiguous(), group=ctx.group)
-        return out, None
+        return _all_gather_rows(g, ctx.comm), None
 
 
 class OwnerRowsSum(torch.autograd.Function):
@@ -334,9 +340,9 @@ class DenseLayerFn(torch.autograd.Function):
             return z(LE), z(E), z(W1), W1.new_zeros(W1.shape[0]), z(W2), W2.new_zeros(W2.shape[0]), None
         dM = ag._bwd_pre(dN.contiguous() if dN is not None else None, dC.contiguous() if dC is not None else None, carry,
                          _eng.LEAKY_SLOPE, 0.0, 0)
-        gW, gb = ag._bwd_weight(dM, LE, E, ctx.ws)
+        gW1, gb1, gW2, gb2 = ag._bwd_weight(dM, LE, E, ctx.ws)
         dLE, dE = ag._bwd_input(dM, W1, W2, LE, E, ctx.ws)
-        return dLE, dE, gW[:, :d_in].contiguous(), 2.0 * gb, gW[:, d_in:].contiguous(), gb, None
+        return dLE, dE, gW1, gb1, gW2, gb2, None
 
 
 class _SumGrads(torch.autograd.Function):
@@ -464,6 +470,61 @@ class P2PExchange:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class P2PCollectives:
+    """All-gather and reduce-scatter of row blocks over a `P2PExchange` of its own: the exchange steps of the TRAINING path (forward
+    and backward) without a collective kernel on the CUs.  Every call uses the next of four regions of the exchange buffer and its
+    sequence slot in turn (all ranks issue the same sequence of calls), so a producer overwrites a region only after every peer has
+    read what it held four calls earlier.  The host blocks in each call until the peers have published (no pipelining here)."""
+
+    REGIONS = 4
+
+    def __init__(self, group, device, region_floats: int):
+        self.region = int(region_floats)
+        self.ex = P2PExchange(group, device, self.REGIONS * self.region)
+        self.rank, self.world, self.dev = self.ex.rank, self.ex.world, self.ex.dev
+        self._op, self._last = 0, {}
+
+    def _stage(self, t: torch.Tensor):
+        """The tensor into the next region of this rank's exchange buffer, published; returns (slot, seq, region offset)."""
+        assert t.dtype == torch.float32 and t.numel() <= self.region, "P2PCollectives: block larger than a region"
+        reg = self._op % self.REGIONS
+        self._op += 1
+        slot, seq, off = 32 + reg, self._op, reg * self.region
+        self.ex.wait_acks(slot, self._last.get(slot, 0))
+        self.ex.floats(off, t.numel()).view(t.shape).copy_(t)
+        self.ex.publish(slot, seq)
+        self._last[slot] = seq
+        self.ex.fence()                          # the copies below land in fresh tensors: after whatever used that memory before
+        return slot, seq, off
+
+    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        send = send.contiguous()
+        m, d = send.shape
+        slot, seq, off = self._stage(send)
+        full = torch.empty((self.world * m, d), dtype=torch.float32, device=self.dev)
+        for q in self.ex.peers_from(self.rank):
+            self.ex.pull(q, slot, seq, off, full[q * m:(q + 1) * m])
+            self.ex.ack(q, slot, seq)
+        self.ex.join()
+        return full
+
+    def reduce_scatter(self, full: torch.Tensor) -> torch.Tensor:
+        full = full.contiguous()
+        m, d = full.shape[0] // self.world, full.shape[1]
+        slot, seq, off = self._stage(full)
+        if (m * d) % 4:
+            raise RuntimeError("P2PCollectives.reduce_scatter: a rank's block must be a multiple of 4 floats")
+        slots = torch.empty((self.world, m, d), dtype=torch.float32, device=self.dev)
+        for q in self.ex.peers_from(self.rank):
+            self.ex.pull(q, slot, seq, off + self.rank * m * d, slots[q])
+            self.ex.ack(q, slot, seq)
+        self.ex.join()
+        own = torch.empty((m, d), dtype=torch.float32, device=self.dev)
+        with _eng._on(self.dev):
+            _lib.check(_lib.load().ngcf_sum_slots_f32(_eng._ptr(slots), m * d, self.world, m * d, _eng._ptr(own), _eng._stream()))
+        return own
 
 
 # ------------------------------------------------------------------------------------------------
@@ -675,13 +736,26 @@ class ShardedPropagation:
         with torch.no_grad():
             return self._propagate_bipartite() if self.mode == "bipartite" else self._propagate_allgather()
 
+    def _train_comm(self):
+        """What the differentiable exchange steps run on: the process group (torch.distributed collectives), or - when this
+        object's transport is p2p - a `P2PCollectives` over an exchange buffer of its own, created on first use."""
+        if self.backend != "p2p":
+            return self.group
+        if getattr(self, "_p2p_train", None) is None:
+            widths = [self.model.emb_size] + list(self.model.weight_size)
+            ldmax = max((d + 31) // 32 * 32 for d in widths)
+            self._p2p_train = P2PCollectives(self.group, self.dev, self.PI * ldmax)
+        return self._p2p_train
+
     def _propagate_bipartite_train(self):
         """The bipartite scheme as a composition of differentiable pieces: `SpmmFn` (the two CSRs of a rank are each other's
         transposes), `DenseLayerFn` (hand-written backward kernels), `ReduceScatterRows` / `AllGatherRows` (each the other's
-        adjoint).  Eval-mode semantics (no dropout).  The exchange uses torch.distributed collectives in both directions.
+        adjoint).  Eval-mode semantics (no dropout).  The exchange steps run over this object's transport in both directions
+        (`_train_comm`: the CU-free p2p collectives, or torch.distributed).
         Gradients: every rank's backward yields the contribution of the rows it owns; `_SumGrads` adds them over the ranks, so
         after `loss.backward()` all ranks hold the same, complete `.grad` for every parameter - as after a single-GPU step."""
         m, g = self.model, self.group
+        comm = self._train_comm()
         r, W, mi, PI = self.rank, self.world, self.mi, self.PI
         lo, nu, ni = self.ub[r], self.nu, self.ni
         n_layer = m.n_layer
@@ -701,7 +775,7 @@ class ShardedPropagation:
         blocks_u, blocks_i = [eu], [ei[own]]
         for k in range(n_layer):
             part = SpmmFn.apply(eu, self.csr_it, self.csr_u, self.ws)               # item partial sums over the local users
-            le_own = ReduceScatterRows.apply(part, g)                                # [mi, d]: the owned items, summed over ranks
+            le_own = ReduceScatterRows.apply(part, comm)                             # [mi, d]: the owned items, summed over ranks
             le_u = SpmmFn.apply(ei, self.csr_u, self.csr_it, self.ws)               # user rows, fully local
             cu, nrm_u = DenseLayerFn.apply(le_u, eu, w1[k], b1[k], w2[k], b2[k], self.ws)
             ci, nrm_i = DenseLayerFn.apply(le_own[:ni], ei[own], w1[k], b1[k], w2[k], b2[k], self.ws)
@@ -710,7 +784,7 @@ class ShardedPropagation:
             if k + 1 < n_layer:
                 send = torch.zeros((mi, ci.shape[1]), dtype=torch.float32, device=self.dev)
                 send = torch.cat([ci, send[ni:]], 0) if ni < mi else ci
-                ei = AllGatherRows.apply(send, g)
+                ei = AllGatherRows.apply(send, comm)
             eu = cu
         self.allE_u, self.allE_i = torch.cat(blocks_u, 1), torch.cat(blocks_i, 1)
         return self.allE_u, self.allE_i
@@ -952,10 +1026,41 @@ class ShardedPropagation:
         return allE_u, allE_i
 
     # -- gathers + BPR (NGCF.py:151-156, bprloss.py:15-22) ---------------------------------------
+    def _gather_inference(self, u_id, pos_item, neg_item):
+        """The three row gathers with ONE exchange: every rank copies the rows it owns into a zero-filled [Bu + Bp + Bn, D] buffer
+        (ngcf_gather_rows_f32 skips ids outside the rank's range: the status word of that call is a throw-away) and one all-reduce
+        adds the buffers - x + 0 is exact, so every rank ends up with the owners' bits."""
+        lib = _lib.load()
+        r = self.rank
+        if self.mode == "bipartite":
+            u_lo, u_n, i_lo, i_n = self.ub[r], self.nu, self.ib[r], self.ni
+        else:
+            u_lo, u_n, i_lo, i_n = self.layout.ub[r], self.nu, self.layout.ib[r] - self.U, self.ni
+        sets = [(self.allE_u, u_id, u_lo, u_n), (self.allE_i, pos_item, i_lo, i_n)]
+        if neg_item is not None:
+            sets.append((self.allE_i, neg_item, i_lo, i_n))
+        D = int(self.allE_u.shape[1])
+        sizes = [int(ix.numel()) for _, ix, _, _ in sets]
+        buf = torch.zeros((sum(sizes), D), dtype=torch.float32, device=self.dev)
+        scrap = self._buf(("scrap_status",), (1,)).view(torch.int32)
+        at = 0
+        with _eng._on(self.dev):
+            for (table, ix, lo, n_rows), b in zip(sets, sizes):
+                if n_rows and b:
+                    loc = (ix.to(torch.int64) - lo).contiguous()
+                    _lib.check(lib.ngcf_gather_rows_f32(_eng._ptr(table), _eng._row_major_ld(table, "table"), D, _eng._ptr(loc), b, 0, n_rows,
+                                                        _eng._ptr(buf[at:at + b]), D, _eng._ptr(scrap), _eng._stream()))
+                at += b
+        dist.all_reduce(buf, group=self.group)
+        outs = torch.split(buf, sizes)
+        return outs[0], outs[1], (outs[2] if neg_item is not None else torch.empty(0))
+
     def gather(self, u_id: torch.Tensor, pos_item: torch.Tensor, neg_item: torch.Tensor):
         """(u, pos, neg) `[B, D]` on every rank.  Rows are served by their owning rank and summed."""
         dev = self.dev
         u_id, pos_item = u_id.to(dev), pos_item.to(dev)
+        if not (torch.is_grad_enabled() and (self.allE_u.requires_grad or self.allE_i.requires_grad)):
+            return self._gather_inference(u_id, pos_item, neg_item.to(dev) if len(neg_item) > 0 else None)
 
         def served(table, owner, local, n_rows):
             mine = owner == self.rank

@@ -177,8 +177,10 @@ def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
     mk = lambda n, d: torch.randn((n, d + (12 if strided else 0)), generator=g, device=dev)[:, :d]  # noqa: E731
     dM, LE, E = mk(n_rows, d_out), mk(n_rows, d_in), mk(n_rows, d_in)
     ws = engine.Workspace()
-    got, gb = autograd._bwd_weight(dM, LE, E, ws)
-    assert got.shape == (d_out, 2 * d_in) and gb.shape == (d_out,)
+    g1, gb1, g2, gb = autograd._bwd_weight(dM, LE, E, ws)
+    assert g1.shape == (d_out, d_in) and g2.shape == (d_out, d_in) and gb.shape == (d_out,)
+    got = torch.cat([g1, g2], 1)
+    assert torch.equal(gb1, 2.0 * gb)
     SP = torch.cat([LE.double() + E.double(), LE.double() * E.double()], 1)
     want = dM.double().t() @ SP
     scale = max(float(want.abs().max()), 1.0) if n_rows else 1.0
@@ -186,8 +188,8 @@ def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
     # the bias gradient (column sums of dM) from the same pass
     want_b = dM.double().sum(0)
     assert float((gb.double() - want_b).abs().max()) <= 2e-5 * max(float(want_b.abs().max()), 1.0)
-    again, gb2 = autograd._bwd_weight(dM, LE, E, ws)
-    assert torch.equal(got, again) and torch.equal(gb, gb2)             # fixed summation order
+    a1, _, a2, gb2 = autograd._bwd_weight(dM, LE, E, ws)
+    assert torch.equal(got, torch.cat([a1, a2], 1)) and torch.equal(gb, gb2)             # fixed summation order
 
 
 @pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(1, 4, 4, False), (130, 128, 128, False), (1000, 130, 128, True), (333, 65, 64, True),
@@ -212,7 +214,7 @@ def test_fused_input_gradient_kernel_vs_torch(n_rows, d_in, d_out, strided, dev)
 
 
 @pytest.mark.parametrize("node_mode", [None, "reference", "device"])
-def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
+def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev, monkeypatch):
     """The last layer's backward on the <= 3 B gathered rows only (compacted dense kernels + ngcf_spmm_t_rows_f32 for
     L^T . dLE) against the dense path (full SpMM on the transposed CSR): same gradients up to the summation order;
     with and without node dropout (thinned matrices in both modes) and with device-mode message dropout (hash by matrix row)."""
@@ -227,6 +229,7 @@ def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
                  pos_item=r(300), neg_item=r(300))
     batch["pos_item"][:20] = 0                                     # a heavy item row several times, duplicates in the batch
     grads = []
+    monkeypatch.setattr(ag, "DENSE_GRAD_MAX_BYTES", 0)             # (a graph this small would get a dense gradient: force the row-sparse form)
     for sparse in (True, False):
         torch.manual_seed(21)
         model = pkg.NGCF(130, [128, 64], 0.3, [0.2, 0.2], 1.0, [pkg.graphs.to_sparse_coo(coo)], num_dict, B, dev).to(dev)
@@ -248,7 +251,7 @@ def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev):
         np.testing.assert_allclose(grads[0][k].cpu().numpy(), grads[1][k].cpu().numpy(), atol=2e-5 * scale, rtol=1e-4, err_msg=k)
 
 
-def test_one_layer_model_at_embed_515_trains(dev):
+def test_one_layer_model_at_embed_515_trains(dev, monkeypatch):
     """A one-layer model at the reference-legal embed_size 515 (515 -> [64]): the last layer's input is 515 wide, beyond the
     512 columns a lane of the row-sparse L^T product holds (it runs as two column panels) - same gradients as with the
     row-sparse path switched off."""
@@ -262,6 +265,7 @@ def test_one_layer_model_at_embed_515_trains(dev):
     batch = dict(year=torch.full((B,), 18, device=dev), u_id=r(900), age=r(76), sex=r(2), month=r(13), day=r(32), dow=r(7),
                  pos_item=r(60), neg_item=r(60))
     grads = []
+    monkeypatch.setattr(ag, "DENSE_GRAD_MAX_BYTES", 0)             # force the row-sparse form on this small graph
     try:
         for sparse in (True, False):
             torch.manual_seed(2)
@@ -314,12 +318,15 @@ def test_row_sparse_transposed_product_vs_dense(d, heavy, drop, dev):
     assert float((again - want).abs().max()) <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("node_mode", [None, "reference", "device"])
-def test_training_gradients_are_bit_identical_from_run_to_run(node_mode, dev):
+@pytest.mark.parametrize("node_mode,dense_grad", [(None, True), ("reference", True), ("device", True), (None, False), ("device", False)])
+def test_training_gradients_are_bit_identical_from_run_to_run(node_mode, dense_grad, dev, monkeypatch):
     """Two training steps from the same seed on the same batch (duplicate users and items in it) give bit-identical gradients of
     every parameter: the gather backward sums duplicates in batch order, L^T . dLE of the row-sparse last layer runs in entry order,
     the weight gradients add their partials in workgroup order - no float atomics anywhere (the reference on CPU is deterministic too)."""
     pkg = _pkg()
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    if not dense_grad:                                             # the row-sparse hand-over of larger graphs (one host sync), forced here
+        monkeypatch.setattr(ag, "DENSE_GRAD_MAX_BYTES", 0)
     coo = pkg.graphs.synthetic_bipartite(4000, 300, 60000, seed=8, device=dev)
     num_dict = {"user": 4000, "item": 300, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
     B = 256
