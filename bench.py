@@ -145,7 +145,8 @@ def cpu_baseline(coo, model, n_threads, seed=0):
             "sample": f"1 of 3 layers (SpMM + 3 Linear + LeakyReLU + normalize + cat) of the same graph, "
                       f"nnz(L)={coo['nnz']}, d={sd['user_embedding.weight'].shape[1]}, torch {torch.__version__} CPU; "
                       f"1 warm-up + 3 timed runs, median {dt:.1f} s at {n_threads} threads "
-                      f"(the sparse mm is single-threaded in torch CPU)",
+                      f"(16 of the node's host CPUs = a one-GPU box's share; the sparse mm is single-threaded in torch CPU, so more threads change "
+                      f"nothing: 1 thread is within a few percent, see one_thread)",
             "seconds": dt, "runs_seconds": [round(t, 2) for t in times],
             "one_thread": {"value": coo["nnz"] / dt1, "unit": "edges/s", "cores": 1, "seconds": dt1,
                            "runs_seconds": [round(t, 2) for t in times1]}}

@@ -90,8 +90,10 @@ int ngcf_csr_plan(ngcf_csr_t *csr, int32_t seg_len, void *stream);
  * row-wise kernels on the rest - meant for long-lived matrices (the Laplacians of `lap_list`): building the plan
  * costs a host pass over the entries and as much device memory again as the CSR.  Calls whose width is not a
  * multiple of 64, that use edge dropout, or whose table spans more than 4 GiB use the row-wise kernels anyway.
- * A CSR with swept parts carries ONE block of sweep counters: products of the same CSR must not run concurrently on two
- * streams (results stay correct - the counters only pace the sweep - but both products lose their L2 re-use). */
+ * A CSR with swept parts keeps a block of sweep counters per launching stream (up to four): products of the same CSR may run
+ * concurrently on different streams (beyond four streams the extra ones share a block: results stay correct - the counters
+ * only pace the sweep - but those products lose L2 re-use).  The stream registry is not thread-safe: launch a given CSR from one
+ * host thread. */
 int ngcf_csr_set_mode(ngcf_csr_t *csr, int mode, void *stream);
 /*
  * Thinned copy of a CSR, made on the device: *dst keeps, in src's order, every stored entry e of `src` with

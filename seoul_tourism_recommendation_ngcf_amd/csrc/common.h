@@ -173,7 +173,11 @@ struct ngcf_csr {
         std::vector<char> group_swept;     // per entry of `groups`: handled by a part
         SegSet out;                        // segments of the cut rows that no part covers
         int64_t n_partial = 0;             // partial rows of all parts (they follow out.n_seg in the workspace)
-        uint32_t *barrier = nullptr;       // device [8*32] per-XCD sweep counters (zeroed before each launch)
+        // device [kSweptStreams][8*32] per-XCD sweep counters (zeroed before each launch): one block per stream that has
+        // launched products of this CSR, so two streams multiplying the same matrix at once do not pace each other's sweep
+        uint32_t *barrier = nullptr;
+        mutable hipStream_t barrier_owner[4] = {nullptr, nullptr, nullptr, nullptr};
+        mutable int barrier_used = 0;
         int built_mode = 0;
     } swept;
 };

@@ -528,7 +528,7 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
         if (rc == NGCF_OK) rc = upload(&w.out.heavy_row, heavy_row, stream);
         if (rc == NGCF_OK) rc = upload(&w.out.heavy_seg_ptr, heavy_ptr, stream);
     }
-    if (rc == NGCF_OK && (hipMalloc(&w.barrier, sizeof(uint32_t) * 32 * 8) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
+    if (rc == NGCF_OK && (hipMalloc(&w.barrier, sizeof(uint32_t) * 32 * 8 * 4) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
         rc = fail(NGCF_ERR_HIP, "swept plan: allocation failed");
     if (rc != NGCF_OK) free_swept(c);
     return rc;
@@ -851,7 +851,15 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
                                                 p.n_rowpass, p.n_win, lead};
         }
         const int waves = w.parts[p0].waves;
-        HIP_TRY(hipMemsetAsync(w.barrier, 0, sizeof(uint32_t) * 32 * 8, stream));
+        // this stream's block of sweep counters (up to four streams per CSR get one of their own; a fifth shares the last)
+        int bi = 0;
+        for (; bi < w.barrier_used && w.barrier_owner[bi] != stream; ++bi) {}
+        if (bi == w.barrier_used) {
+            if (w.barrier_used < 4) w.barrier_owner[w.barrier_used++] = stream;
+            else bi = 3;
+        }
+        unsigned *bar_blk = w.barrier + (size_t)bi * 32 * 8;
+        HIP_TRY(hipMemsetAsync(bar_blk, 0, sizeof(uint32_t) * 32 * 8, stream));
         unsigned long long *dbg = nullptr;
 #ifdef NGCF_LAB
         const size_t dbg_words = (size_t)kSweptWGs * waves * (2 * kDbgSamples + 2);
@@ -861,7 +869,7 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
         }
 #endif
 #define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_, DROP_)                                                                                    \
-    spmm_swept_kernel<RW_, NW_, DBG_, DROP_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, w.barrier,  \
+    spmm_swept_kernel<RW_, NW_, DBG_, DROP_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, bar_blk,    \
                                                                                       max_spin, sync_k, prio_cols, prio_graded,    \
                                                                                       nt_flags, dbg, dr)
 #ifdef NGCF_LAB

@@ -487,44 +487,43 @@ class P2PCollectives:
         self._op, self._last = 0, {}
 
     def _stage(self, t: torch.Tensor):
-        """The tensor into the next region of this rank's exchange buffer, published; returns (slot, seq, region offset)."""
-        assert t.dtype == torch.float32 and t.numel() <= self.region, "P2PCollectives: block larger than a region"
+        """The rows of `t` [n, d] into the next region of this rank's exchange buffer (row stride d4 = d rounded up to 4 floats:
+        every rank's block is then a whole number of 16-byte pieces), published; returns (slot, seq, region offset, d4)."""
+        n, d = t.shape
+        d4 = (d + 3) // 4 * 4
+        assert t.dtype == torch.float32 and n * d4 <= self.region, "P2PCollectives: block larger than a region"
         reg = self._op % self.REGIONS
         self._op += 1
         slot, seq, off = 32 + reg, self._op, reg * self.region
         self.ex.wait_acks(slot, self._last.get(slot, 0))
-        self.ex.floats(off, t.numel()).view(t.shape).copy_(t)
+        self.ex.floats(off, n * d4).view(n, d4)[:, :d].copy_(t)
         self.ex.publish(slot, seq)
         self._last[slot] = seq
         self.ex.fence()                          # the copies below land in fresh tensors: after whatever used that memory before
-        return slot, seq, off
+        return slot, seq, off, d4
 
     def all_gather(self, send: torch.Tensor) -> torch.Tensor:
-        send = send.contiguous()
         m, d = send.shape
-        slot, seq, off = self._stage(send)
-        full = torch.empty((self.world * m, d), dtype=torch.float32, device=self.dev)
+        slot, seq, off, d4 = self._stage(send)
+        full = torch.empty((self.world * m, d4), dtype=torch.float32, device=self.dev)
         for q in self.ex.peers_from(self.rank):
             self.ex.pull(q, slot, seq, off, full[q * m:(q + 1) * m])
             self.ex.ack(q, slot, seq)
         self.ex.join()
-        return full
+        return full[:, :d]
 
     def reduce_scatter(self, full: torch.Tensor) -> torch.Tensor:
-        full = full.contiguous()
         m, d = full.shape[0] // self.world, full.shape[1]
-        slot, seq, off = self._stage(full)
-        if (m * d) % 4:
-            raise RuntimeError("P2PCollectives.reduce_scatter: a rank's block must be a multiple of 4 floats")
-        slots = torch.empty((self.world, m, d), dtype=torch.float32, device=self.dev)
+        slot, seq, off, d4 = self._stage(full)
+        slots = torch.empty((self.world, m, d4), dtype=torch.float32, device=self.dev)
         for q in self.ex.peers_from(self.rank):
-            self.ex.pull(q, slot, seq, off + self.rank * m * d, slots[q])
+            self.ex.pull(q, slot, seq, off + self.rank * m * d4, slots[q])
             self.ex.ack(q, slot, seq)
         self.ex.join()
-        own = torch.empty((m, d), dtype=torch.float32, device=self.dev)
+        own = torch.empty((m, d4), dtype=torch.float32, device=self.dev)
         with _eng._on(self.dev):
-            _lib.check(_lib.load().ngcf_sum_slots_f32(_eng._ptr(slots), m * d, self.world, m * d, _eng._ptr(own), _eng._stream()))
-        return own
+            _lib.check(_lib.load().ngcf_sum_slots_f32(_eng._ptr(slots), m * d4, self.world, m * d4, _eng._ptr(own), _eng._stream()))
+        return own[:, :d]                        # (the padding columns carry whatever the regions held: never read)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -619,10 +618,13 @@ class ShardedPropagation:
             ld = lambda d: (d + 31) // 32 * 32                     # noqa: E731
             self._ld_in, self._ld_out = max(ld(d) for d in widths[:-1]), max(ld(d) for d in widths[1:])
             if self.backend == "p2p":
-                # exchange buffer: [partial sums of all items] x 2, [carry rows of the owned items] x 2 (two steps in turn)
-                self._off_part = [0, self.PI * self._ld_in]
-                self._off_carry = [2 * self.PI * self._ld_in, 2 * self.PI * self._ld_in + mi * self._ld_out]
-                self.p2p = self._open_p2p(group, dev, 2 * self.PI * self._ld_in + 2 * mi * self._ld_out)
+                # exchange buffer: per LAYER a region for the partial sums of all items and one for the carry rows of the owned
+                # items.  Nothing is overwritten inside a pass, so the peers acknowledge once per pass (not per pull round): a
+                # pass starts by waiting for the previous pass's acknowledgements.
+                nl = len(widths) - 1
+                self._off_part = [k * self.PI * self._ld_in for k in range(nl)]
+                self._off_carry = [nl * self.PI * self._ld_in + k * mi * self._ld_out for k in range(nl)]
+                self.p2p = self._open_p2p(group, dev, nl * (self.PI * self._ld_in + mi * self._ld_out))
         else:
             cnt = torch.cat([deg_u.to("cpu", torch.int64), deg_i.to("cpu", torch.int64)])
             ub = balanced_bounds(cnt, 0, U, W)
@@ -825,25 +827,25 @@ class ShardedPropagation:
         gloo = dist.get_backend(self.group) != "nccl"
         off = d0
         pending = None                                             # the all-gather of the previous layer's item carry
+        ACK = 62                                                   # the one acknowledgement slot: "I have read everything of pass n"
+        if ex is not None:
+            ex.wait_acks(ACK, self._calls - 1)                     # every peer is done with what the previous pass left in my buffer
         for k in range(n_layer):
             d_in, d_out = widths[k], widths[k + 1]
             last = k == n_layer - 1
-            seq, par = base + k + 1, k % 2
-            sp, sc = 2 * par, 2 * par + 1                          # sequence slots: partial sums / carry of this parity
+            seq = base + k + 1
+            sp, sc = 2 * k, 2 * k + 1                              # sequence slots: partial sums / carry of this layer
             if ex is not None:
                 ex.fence()                                         # copies of this layer start after the previous layer's readers
                 # -- A: item partial sums over the local users, into the exchange buffer
-                ex.wait_acks(sp, self._last_pub.get(sp, 0))
-                part = ex.floats(self._off_part[par], PI * ld(d_in)).view(PI, ld(d_in))[:, :d_in]
+                part = ex.floats(self._off_part[k], PI * ld(d_in)).view(PI, ld(d_in))[:, :d_in]
                 _eng.spmm(self.csr_it, eu, out=part, ws=self.ws)
                 ex.publish(sp, seq)
-                self._last_pub[sp] = seq
                 # -- the previous layer's item carry arrives while A runs
                 if pending is not None:
                     nxt_ei, pseq, psc, pld = pending
                     for q in ex.peers_from(r):
-                        ex.pull(q, psc, pseq, self._off_carry[(k - 1) % 2], nxt_ei[q * mi:(q + 1) * mi])
-                        ex.ack(q, psc, pseq)
+                        ex.pull(q, psc, pseq, self._off_carry[k - 1], nxt_ei[q * mi:(q + 1) * mi])
                     ex.join()
                     ei = nxt_ei[:, :d_in]
                     pending = None
@@ -866,8 +868,9 @@ class ShardedPropagation:
             if ex is not None:
                 slots = self._buf(("slots", k), (W, mi, ld(d_in)))
                 for q in ex.peers_from(r):
-                    ex.pull(q, sp, seq, self._off_part[par] + r * mi * ld(d_in), slots[q])
-                    ex.ack(q, sp, seq)
+                    ex.pull(q, sp, seq, self._off_part[k] + r * mi * ld(d_in), slots[q])
+                    if last:
+                        ex.ack(q, ACK, self._calls)                # the last copy of this pass from rank q is enqueued
                 ex.join()
                 le_own = self._buf(("le_own", k), (mi, ld(d_in)))
                 with _eng._on(self.dev):
@@ -881,8 +884,7 @@ class ShardedPropagation:
             if last:
                 ci = None
             elif ex is not None:
-                ex.wait_acks(sc, self._last_pub.get(sc, 0))
-                ci = ex.floats(self._off_carry[par], mi * ld(d_out)).view(mi, ld(d_out))
+                ci = ex.floats(self._off_carry[k], mi * ld(d_out)).view(mi, ld(d_out))
             else:
                 ci = self._buf(("ci", k), (mi, ld(d_out)))
             if ni:
@@ -892,7 +894,6 @@ class ShardedPropagation:
                 nxt_ei = self._buf(("ei", k + 1), (PI, ld(d_out)))
                 if ex is not None:
                     ex.publish(sc, seq)
-                    self._last_pub[sc] = seq
                     pending = (nxt_ei, seq, sc, ld(d_out))         # pulled at the top of the next layer, under its A
                 else:
                     pending = dist.all_gather_into_tensor(nxt_ei, ci, group=self.group, async_op=True)

@@ -43,8 +43,8 @@ def test_recommend_topk_on_module_outputs():
         model.propagate(0)
         u = model.all_users_emb[torch.tensor([3, 77, 1999], device=dev)]
         vals, idx, scores = pkg.engine.recommend_topk(u, model.all_items_emb, 100, return_scores=True)
-        want = torch.mm(u, model.all_items_emb.T)
-    # the score matrix is the reference's torch.mm within fp32 summation-order noise; the selection is exact on it
+        want = torch.mm(u.cpu(), model.all_items_emb.cpu().T).to(dev)       # the reference's own op on the CPU (demo.py:233-234)
+    # the score matrix is the reference's CPU torch.mm within fp32 summation-order noise; the selection is exact on it
     torch.testing.assert_close(scores, want, atol=1e-5, rtol=1e-5)
     tv, ti = torch.topk(scores, 100)
     assert torch.equal(vals, tv) and torch.equal(torch.gather(scores, 1, idx), vals)
@@ -62,7 +62,7 @@ def test_recommend_topk_kernel_vs_torch(B, n_items, D, k):
     u = torch.randn((B, D), generator=g, device=dev)
     items = torch.randn((n_items + 3, D + 5), generator=g, device=dev)[3:, 2:2 + D]      # a strided, offset view
     vals, idx, scores = eng.recommend_topk(u, items, k, return_scores=True)
-    want = torch.mm(u, items.T)
+    want = torch.mm(u.cpu(), items.cpu().T).to(dev)                  # the reference's op on the CPU (the oracle), not rocBLAS
     torch.testing.assert_close(scores, want, atol=2e-4, rtol=2e-5)
     tv, _ = torch.topk(scores, k)
     assert torch.equal(vals, tv) and torch.equal(torch.gather(scores, 1, idx), vals)
