@@ -79,3 +79,30 @@ def test_c5_rank_slabs_of_eight():
                 np.testing.assert_allclose(carry[row].cpu().numpy(), m.cpu().numpy(), atol=2e-4, rtol=RTOL, err_msg=f"{tag} row {row}")
             del csr, LX, LY, LZ, carry, nrm
         del ur, uc, uv, ir, ic, iv, slabs
+        if rank == 3:
+            # the same rank's slabs in the DEFAULT exchange scheme (bipartite, dist._setup): user rows x item replica in the
+            # owner-major padded numbering, and the transposed slab that forms the item partial sums over the local users
+            ob = nd.even_bounds(0, I, W)
+            mi = max(ob[q + 1] - ob[q] for q in range(W))
+            PI = W * mi
+            eb = nd.balanced_bounds(cnt, 0, U, W)
+            lo, hi = eb[rank], eb[rank + 1]
+            (bur, buc, buv), _ = nd.cut_slabs(u, i, v, U, lo, hi, 0, 0)
+            pos = nd.padded_item_pos(buc - U, ob, mi)
+            csr_u = eng.LaplacianCSR.from_coo(bur - lo, pos, buv, hi - lo, PI)
+            order = torch.sort(pos, stable=True).indices
+            csr_it = eng.LaplacianCSR.from_coo(pos[order], bur[order] - lo, buv[order], PI, hi - lo)
+            assert csr_u.nnz == csr_it.nnz and abs(csr_u.nnz - n_inter / W) < 0.02 * n_inter / W
+            Xi, Xu = X[:PI], X[:hi - lo]
+            for name, csr, tab, (rr, cc, vv) in (("bipartite user rows", csr_u, Xi, (bur - lo, pos, buv)),
+                                                  ("bipartite item partial sums", csr_it, Xu, (pos[order], bur[order] - lo, buv[order]))):
+                out = eng.spmm(csr, tab, ws=ws)
+                out2 = eng.spmm(csr, 3.0 * tab, ws=ws)
+                scale = float(out.abs().max())
+                assert float((out2 - 3.0 * out).abs().max()) <= 2e-5 * max(scale, 1.0), name
+                rows = torch.cat([torch.randint(0, csr.n_rows, (16,), device=dev), torch.topk(torch.bincount(rr, minlength=csr.n_rows), 3).indices])
+                rp = torch.searchsorted(rr, torch.stack([rows, rows + 1]))
+                for row, (a, b) in zip(rows.tolist(), rp.T.tolist()):
+                    want = (vv[a:b].double()[:, None] * tab[cc[a:b]].double()).sum(0)
+                    np.testing.assert_allclose(out[row].cpu().numpy(), want.cpu().numpy(), atol=ATOL, rtol=RTOL, err_msg=f"{name} row {row}")
+            del csr_u, csr_it, bur, buc, buv, pos, order

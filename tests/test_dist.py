@@ -331,6 +331,14 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False, collec
             first = sh.propagate()                                 # would take its differentiable path: tested further down)
             first = (first[0].clone(), first[1].clone())
             au, ai = sh.propagate()                                # a second pass re-uses every buffer and both exchange regions
+            assert torch.equal(au, first[0]) and torch.equal(ai, first[1])
+            import time
+            for it in range(4):                                    # ranks drifting apart: sleeps of 0 / 15 / 30 ms that rotate over the ranks,
+                time.sleep(0.015 * ((rank + it) % 3))              # with and without a device sync - the sequence words and the
+                if (rank + it) % 2:                                # acknowledgements keep producers and consumers in step
+                    torch.cuda.synchronize()
+                au, ai = sh.propagate()
+                assert torch.equal(au, first[0]) and torch.equal(ai, first[1]), f"pass {it + 3} differs"
         assert torch.equal(au, first[0]) and torch.equal(ai, first[1])
         if mode == "bipartite":
             lo, hi = sh.ub[rank], sh.ub[rank + 1]

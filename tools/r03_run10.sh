@@ -1,0 +1,7 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export NGCF_NO_BUILD=1
+mkdir -p gpurun_out/r03
+timeout -k 10 900 python -m pytest tests/test_dist.py tests/test_c4_partition_gpu.py tests/test_c5_slab_gpu.py -m gpu -x -q > gpurun_out/r03/gputests10.log 2>&1
+export NGCF_BENCH_SHARE_GPU=1
+timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 3 --steps 5 --warmup 2 --no-secondary > gpurun_out/r03/bench_c3_3ranks_default.json 2> gpurun_out/r03/bench_c3_3ranks_default.err
