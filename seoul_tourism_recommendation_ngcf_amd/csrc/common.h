@@ -68,6 +68,7 @@ struct NgcfOptions {
     // csr.hip
     int slice_max_mb = 48;         // NGCF_SLICE_MAX_MB: largest table slice a d-sliced group may gather from
     // spmm_swept.hip (plan)
+    int swept_lpe = 16;            // NGCF_SWEPT_LPE: lanes per entry of the swept plan: 16 = 64-float slices, 32 = 128-float slices
     int swept_waves = 0;           // NGCF_SWEPT_WAVES (LAB: 8)
     int swept_cut = 4;             // NGCF_SWEPT_CUT: rows are cut at 1/cut of a wave task's share
     int swept_no_moments = 0;      // NGCF_SWEPT_NO_MOMENTS
@@ -159,6 +160,7 @@ struct ngcf_csr {
         struct Part {                      // one row group handled by the swept kernel
             int64_t row_lo = 0, row_hi = 0;
             int waves = 0, rows_per_wave = 0;          // workgroup shape the entry lists were laid out for
+            int lpe = 16;                              // lanes per entry (16: 64-float slices, 32: 128-float slices)
             int32_t n_rowpass = 0, n_win = 0, win_cols = 0, col_lo = 0, col_hi = 0;
             int64_t n_slots = 0, n_partial = 0, n_heavy = 0, partial_base = 0;   // partial rows: workspace rows base..base+n
             int64_t *tptr = nullptr;           // device [n_tasks*n_win+1] slot range of every (wave task, column window)
@@ -179,6 +181,7 @@ struct ngcf_csr {
         mutable hipStream_t barrier_owner[4] = {nullptr, nullptr, nullptr, nullptr};
         mutable int barrier_used = 0;
         int built_mode = 0;
+        int lpe = 16;                      // geometry of the parts (spmm_swept.hip): lanes per entry
     } swept;
 };
 

@@ -38,6 +38,7 @@ const OptField kOptFields[] = {
     {"dense_resident", &NgcfOptions::dense_resident, nullptr},
     {"dense_small_tiles", &NgcfOptions::dense_small_tiles, nullptr},
     {"slice_max_mb", &NgcfOptions::slice_max_mb, nullptr},
+    {"swept_lpe", &NgcfOptions::swept_lpe, nullptr},
     {"swept_waves", &NgcfOptions::swept_waves, nullptr},
     {"swept_cut", &NgcfOptions::swept_cut, nullptr},
     {"swept_no_moments", &NgcfOptions::swept_no_moments, nullptr},

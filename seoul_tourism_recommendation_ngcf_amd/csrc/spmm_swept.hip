@@ -25,15 +25,16 @@
 #include "spmm_device.h"
 
 namespace {
-constexpr int kLPE = 16;                  // lanes per entry: a 64-float slice of the gathered row
-constexpr int kSW = kLPE * 4;             // floats per slice
-constexpr int kEPR = 64 / kLPE;           // entries per round
-constexpr int kCH = 16 * kEPR;            // entries per chunk (16 rounds)
+// Geometry of a part: LPE lanes share one entry, i.e. a slice of SW = 4 LPE floats of the gathered row per wave instruction;
+// EPR = 64 / LPE entries per round, 16 rounds per chunk.  LPE = 16: 64-float (256-byte) slices, four entries per round, 576
+// accumulator rows per workgroup.  LPE = 32 (r03): 128-float (512-byte) slices - at d = 128 the whole row in ONE sweep, two entries
+// per round, 288 accumulator rows per workgroup: twice the row passes, half the slices, every stored entry read once instead of
+// twice, four consecutive 128-byte lines per gather instead of two.
+constexpr int kLdsBytes = 36 * 16 * 256;  // accumulator bytes per workgroup (144 KiB of LDS, + one spare row per wave)
 constexpr int kSweptWGs = 256;            // one workgroup per CU
 constexpr int kRing = 8;                  // rotating sweep counters per XCD
 constexpr int kRowBits = 24;              // e_pack: column in bits 0..23, local row in bits 24..30
 constexpr int kColMask = (1 << kRowBits) - 1;
-constexpr int kLdsRows = 36 * 16;         // accumulator rows per workgroup (144 KiB of LDS, + one spare row per wave)
 
 template <typename F>
 void parallel_for(int64_t n, F &&fn, int64_t min_parallel = 64)
@@ -96,8 +97,9 @@ struct Piece {
 
 // Plan of the rows [row_lo, row_hi).  Leaves part.waves == 0 when the part is not worth it (mode 3) or the shape does
 // not fit the entry encoding.
-int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hipStream_t stream, ngcf_csr::Swept::Part &part)
+int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hipStream_t stream, ngcf_csr::Swept::Part &part, int LPE)
 {
+    const int kSW = LPE * 4, kEPR = 64 / LPE, kLdsRows = kLdsBytes / (kSW * 4);        // the part's geometry (see the top of the file)
     const int64_t row_lo = grp.begin, row_hi = grp.end, n = row_hi - row_lo;
     const int32_t col_lo = grp.col_lo, col_hi = grp.col_hi;
     if (n <= 0 || col_hi < col_lo) return NGCF_OK;
@@ -426,6 +428,7 @@ int build_part(const ngcf_csr *c, const ngcf_csr::RowGroup &grp, bool force, hip
     part.row_lo = row_lo;
     part.row_hi = row_hi;
     part.rows_per_wave = RW;
+    part.lpe = LPE;
     part.n_rowpass = (int32_t)n_rowpass;
     part.n_win = (int32_t)n_win;
     part.win_cols = win_cols;
@@ -468,6 +471,7 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     free_swept(c);
     ngcf_csr::Swept &w = c->swept;
     w.built_mode = c->mode;
+    w.lpe = ngcf_opts().swept_lpe == 32 ? 32 : 16;
     if (c->mode < 2 || c->n_rows == 0 || c->nnz == 0) return NGCF_OK;
     // the plan is laid out for one resident workgroup on each of 256 CUs in 8 XCDs (an MI355X in SPX mode); on any
     // other partitioning the grid would not be resident together, so the products stay on the row-wise kernels
@@ -486,7 +490,7 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
     w.group_swept.assign(c->groups.size(), 0);
     for (size_t g = 0; g < c->groups.size(); ++g) {
         ngcf_csr::Swept::Part p;
-        const int rc = build_part(c, c->groups[g], c->mode == 2, stream, p);
+        const int rc = build_part(c, c->groups[g], c->mode == 2, stream, p, w.lpe);
         if (rc != NGCF_OK) {
             free_swept(c);
             return rc;
@@ -538,7 +542,7 @@ int build_swept_plan(ngcf_csr *c, hipStream_t stream)
 bool swept_usable(const ngcf_csr *c, int64_t ldE, int d)
 {
     const ngcf_csr::Swept &w = c->swept;
-    if (w.parts.empty() || c->mode < 2 || d % kSW != 0) return false;
+    if (w.parts.empty() || c->mode < 2 || d % (w.lpe * 4) != 0) return false;
     for (const auto &p : w.parts)
         if (((int64_t)p.col_hi + 1) * ldE * 4 > (int64_t)UINT32_MAX) return false;
     return true;
@@ -575,20 +579,22 @@ struct SweptLaunch {
 // DROP: device-mode node dropout (common.h, EdgeDrop): a lane tests the entry it holds when it loads it - row from the wave's
 // table of matrix rows (one ds_bpermute), column from the packed entry - and zeroes the value of a dropped entry; the gather of
 // a dropped entry still happens (the round structure is fixed by the plan), its product is 0.
-template <int RW, int NW, bool DBG, bool DROP>
+template <int LPE, int RW, int NW, bool DBG, bool DROP>
 __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int n_slices, const float *__restrict__ E,
                                                              int64_t ldE, float *__restrict__ out, int64_t ldo, int dp, unsigned *bar,
                                                              int max_spin, int sync_k, unsigned prio_cols, int prio_graded, int nt_flags,
                                                              unsigned long long *__restrict__ dbg, EdgeDrop dr)
 {
+    constexpr int kSW = LPE * 4, kEPR = 64 / LPE, kCH = 16 * kEPR;
     __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];
     __shared__ int perm_lds;                    // highest sweep step this workgroup knows to be permitted
     __shared__ unsigned xcc_id;
     __shared__ unsigned wg_front;               // furthest (sweep, column) any wave of this workgroup has reached
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane >> 4, p = lane & 15;     // entry slot in the round, position in the slice
-    const int held = p * kEPR + g;              // chunk entry this lane keeps: round u = lane u of every 16-lane row
+    const int g = lane / LPE, p = lane % LPE;   // entry slot in the round, position in the slice
+    // chunk entry this lane keeps: round u = lane u of every 16-lane DPP row (LPE = 32: the two DPP rows of an entry's lanes hold it twice)
+    const int held = (lane & 15) * kEPR + g;
     float *wacc = acc_lds + wave * ((RW + 1) * kSW);
     if (threadIdx.x < kRing) wg_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
@@ -822,6 +828,7 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
     const int lead_env = o.swept_lead;
     const int sync_k = std::max(1, o.swept_sync_every);       // windows per sweep step (lab knob)
     // lag (KiB of table slice) behind the front of its workgroup beyond which a wave raises its priority; 0 = off
+    const int kSW = w.lpe * 4;
     const unsigned prio_cols = (unsigned)std::max(0, o.swept_prio_kb) * 1024u / (kSW * 4);
     // graded: priority 1 / 2 / 3 beyond 1x / 2x / 4x the threshold (C3 item rows 1.50 vs 1.61 ms against one step to 3)
     const int prio_graded = o.swept_prio_graded;
@@ -868,22 +875,24 @@ int launch_swept(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *o
             HIP_TRY(hipMemsetAsync(dbg, 0, dbg_words * 8, stream));
         }
 #endif
-#define NGCF_SWEPT_LAUNCH(RW_, NW_, DBG_, DROP_)                                                                                    \
-    spmm_swept_kernel<RW_, NW_, DBG_, DROP_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, bar_blk,    \
+#define NGCF_SWEPT_LAUNCH(LPE_, RW_, NW_, DBG_, DROP_)                                                                                    \
+    spmm_swept_kernel<LPE_, RW_, NW_, DBG_, DROP_><<<dim3(kSweptWGs), NW_ * 64, 0, stream>>>(L, d / kSW, E, ldE, out, ldo, dp, bar_blk, \
                                                                                       max_spin, sync_k, prio_cols, prio_graded,    \
                                                                                       nt_flags, dbg, dr)
 #ifdef NGCF_LAB
         if (waves == 8) {
-            if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false, true);
-            else if (trace) NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, true, false);
-            else NGCF_SWEPT_LAUNCH(kLdsRows / 8, 8, false, false);
+            if (dr.n > 0) NGCF_SWEPT_LAUNCH(16, 72, 8, false, true);
+            else if (trace) NGCF_SWEPT_LAUNCH(16, 72, 8, true, false);
+            else NGCF_SWEPT_LAUNCH(16, 72, 8, false, false);
         } else if (trace && dr.n == 0) {
-            NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, true, false);
+            NGCF_SWEPT_LAUNCH(16, 36, 16, true, false);
         } else
 #endif
         if (waves != 16) return fail(NGCF_ERR_ARG, "swept: the plan's workgroup shape (%d waves) is not compiled into this library", waves);
-        else if (dr.n > 0) NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, true);
-        else NGCF_SWEPT_LAUNCH(kLdsRows / 16, 16, false, false);
+        else if (w.lpe == 32 && dr.n > 0) NGCF_SWEPT_LAUNCH(32, 18, 16, false, true);
+        else if (w.lpe == 32) NGCF_SWEPT_LAUNCH(32, 18, 16, false, false);
+        else if (dr.n > 0) NGCF_SWEPT_LAUNCH(16, 36, 16, false, true);
+        else NGCF_SWEPT_LAUNCH(16, 36, 16, false, false);
 #undef NGCF_SWEPT_LAUNCH
         LAUNCH_CHECK();
 #ifdef NGCF_LAB

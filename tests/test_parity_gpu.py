@@ -315,12 +315,13 @@ def test_default_segment_length_follows_the_matrix_size(dev, oracle_clib):
     assert small.n_segments == sum(-(-int(k) // 64) for k in np.bincount(rows[:5000], minlength=N) if k > 64)
 
 
-@pytest.mark.parametrize("d,order", [(64, "cols"), (128, "cols"), (256, "cols"), (128, "rows"), (576, "cols")])
-def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, lib_options):
+@pytest.mark.parametrize("d,order,lpe", [(64, "cols", 16), (128, "cols", 16), (256, "cols", 16), (128, "rows", 16), (576, "cols", 16),
+                                         (128, "cols", 32), (256, "cols", 32), (128, "rows", 32), (384, "cols", 32)])
+def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, lpe, dev, lib_options):
     """Bipartite matrix: the user rows (small gathered table) run d-sliced, the item rows unsliced; the L2-swept
     kernel (forced; both layouts of a wave's entry list inside a window) and the plain row-wise kernel must give the
     same product."""
-    lib_options(swept_order_rows=int(order == "rows"))
+    lib_options(swept_order_rows=int(order == "rows"), swept_lpe=lpe)      # lpe 32: 128-float slices, two entries per round
     pkg = _pkg()
     eng = pkg.engine
     coo = pkg.graphs.synthetic_bipartite(150000, 12000, 2600000, seed=33, device=dev)
@@ -352,7 +353,8 @@ def test_spmm_sliced_and_swept_kernels_large_matrix(d, order, dev, lib_options):
         np.testing.assert_allclose(swept[r].detach().cpu().numpy(), want.detach().cpu().numpy(), atol=ATOL, rtol=RTOL)
 
 
-def test_spmm_swept_many_rows_several_row_passes(dev):
+@pytest.mark.parametrize("lpe,d", [(16, 64), (32, 128)])
+def test_spmm_swept_many_rows_several_row_passes(lpe, d, dev, lib_options):
     """More output rows than the chip's LDS holds at once: several row passes (16 waves x 36 rows per workgroup; the 8 x 72
     shape of round 1 is a lab instantiation, compiled only with -DNGCF_LAB).  Also a group with a handful of very long rows
     (cut into strided pieces) and duplicate entries inside a row."""
@@ -365,8 +367,9 @@ def test_spmm_swept_many_rows_several_row_passes(dev):
     rows, cols, vals = torch.cat([rows, rows[dup]]), torch.cat([cols, cols[dup]]), torch.cat([vals, vals[dup]])
     order = torch.sort(rows, stable=True).indices
     rows, cols, vals = rows[order], cols[order], vals[order]
+    lib_options(swept_lpe=lpe)
     csr = eng.LaplacianCSR.from_coo(rows, cols, vals, N, N)
-    X = torch.randn((N, 64), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+    X = torch.randn((N, d), generator=torch.Generator(device=dev).manual_seed(5), device=dev)
     rowwise = eng.spmm(csr, X)
     csr.set_mode(2)
     assert csr.swept_rows == N
@@ -378,15 +381,17 @@ def test_spmm_swept_many_rows_several_row_passes(dev):
 
 @pytest.mark.parametrize("n_rows,n_cols,deg,heavy", [(1, 1, 1, ()), (5, 3, 40, ()), (2000, 70000, 1, ()),
                                                       (300, 50000, 3, ((0, 120000), (299, 9000))), (40, 17, 0, ((7, 5000),))])
-def test_spmm_swept_degenerate_shapes(n_rows, n_cols, deg, heavy, dev, oracle_clib):
+@pytest.mark.parametrize("lpe", [16, 32])
+def test_spmm_swept_degenerate_shapes(n_rows, n_cols, deg, heavy, lpe, dev, oracle_clib, lib_options):
     """The swept plan forced onto shapes it was not made for: one entry, a few columns with thousands of duplicates per
     row (rounds = longest row), one entry per row over many windows, a row far longer than everything else together
     (strided pieces + fix-up), everything in one row."""
     eng = _pkg().engine
     rng = np.random.default_rng(n_rows + n_cols)
     rowptr, rows, cols, vals = random_csr(rng, n_rows, n_cols, deg, heavy=heavy)
-    E = rng.normal(0, 0.5, (n_cols, 64)).astype(np.float32)
+    E = rng.normal(0, 0.5, (n_cols, 4 * lpe)).astype(np.float32)     # one slice of the part's geometry
     want = c_spmm(oracle_clib, rowptr, cols.astype(np.int32), vals, E)
+    lib_options(swept_lpe=lpe)
     csr = eng.LaplacianCSR.from_coo(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev),
                                     torch.from_numpy(vals).to(dev), n_rows, n_cols)
     csr.set_mode(2)
