@@ -811,12 +811,16 @@ class ShardedPropagation:
         iw = m.item_embedding.weight.detach()
         _eng.copy_rows(m.user_embedding.weight.detach()[lo:lo + nu], allE_u[:, :d0])
         _eng.copy_rows(iw[self.ib[r]:self.ib[r + 1]], allE_i[:, :d0])
-        # layer-0 item replica from the replicated parameter table (padded numbering): local copies, no communication
+        # layer-0 item replica from the replicated parameter table (padded numbering): local copies, no communication - and none at
+        # all while the table is the same tensor at the same version as in the previous pass (inference loops)
         ei = self._buf(("ei", 0), (PI, ld(d0)))[:, :d0]
-        for q in range(W):
-            n_q = self.ib[q + 1] - self.ib[q]
-            if n_q:
-                _eng.copy_rows(iw[self.ib[q]:self.ib[q + 1]], ei[q * mi:q * mi + n_q])
+        tag = (iw.data_ptr(), m.item_embedding.weight._version, tuple(iw.shape))
+        if getattr(self, "_ei0_tag", None) != tag:
+            for q in range(W):
+                n_q = self.ib[q + 1] - self.ib[q]
+                if n_q:
+                    _eng.copy_rows(iw[self.ib[q]:self.ib[q + 1]], ei[q * mi:q * mi + n_q])
+            self._ei0_tag = tag
         eu = allE_u[:, :d0]
         if d0 % 4 or D % 4:                                        # rows of all_E are not 16-byte aligned: an aligned copy to gather from
             eu = self._buf(("eu0",), (nu, ld(d0)))[:, :d0]
