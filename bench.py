@@ -178,7 +178,7 @@ def cpu_baseline_full(coo, model, n_threads, seed=0):
 TRAIN_CFG = dict(embed=65, layers=(65, 65, 65), node_dropout=0.3, mess_dropout=(0.1, 0.1, 0.1), lr=1e-3, wd=0.025)
 
 
-def seoul_train_setup(pkg, dev, batch, mode, seed=1801):
+def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False):
     """The reference's training configuration (main.py:63-76 + parsers.py defaults) on the Seoul-shaped stand-in graph, and one
     step of experiment.py:45-58: model(node_flag=True) -> zero_grad -> BPR -> backward -> Adam.step, in train mode, with the
     module's defaults otherwise (index check on)."""
@@ -191,7 +191,7 @@ def seoul_train_setup(pkg, dev, batch, mode, seed=1801):
                      [pkg.graphs.to_sparse_coo(x) for x in slices], nd, batch, dev).to(dev)
     model.train()
     model.node_dropout_mode = model.mess_dropout_mode = mode
-    opt = torch.optim.Adam(model.parameters(), lr=c["lr"])
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], capturable=bool(graphed))
     crit = pkg.BPR(c["wd"], batch).to(dev)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     ids = {k: torch.randint(0, hi, (batch,), generator=g).to(dev)
@@ -205,6 +205,9 @@ def seoul_train_setup(pkg, dev, batch, mode, seed=1801):
         loss.backward()
         opt.step()
         return loss
+    if graphed:        # the same step captured once and replayed (opt-in: seoul_tourism_recommendation_ngcf_amd.GraphedTrainStep)
+        gts = pkg.GraphedTrainStep(model, crit, opt, ids, node_flag=True)
+        return model, (lambda: gts(**ids)), slices[0], ids
     return model, step, slices[0], ids
 
 
@@ -258,13 +261,13 @@ def cpu_train_baseline(coo_slices_cpu, n_user, model, ids, batch, n_threads, ste
     return dt, float(loss.detach())
 
 
-def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5):
+def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5, graphed=False):
     """One labelled measurement of the reference's training step in one dropout mode."""
-    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode)
+    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode, graphed=graphed)
     ms, ms_issue, loss = time_train_steps(step, steps, warmup)
     n_layer = len(TRAIN_CFG["layers"])
     return {"ms_per_step": ms, "host_issue_ms_per_step": ms_issue, "value": n_layer * coo["nnz"] / (ms * 1e-3), "unit": "edges/s",
-            "loss": loss, "steps": steps, "dropout_mode": mode,
+            "loss": loss, "steps": steps, "dropout_mode": mode, "hipgraph": bool(graphed),
             "note": f"main.py:63-76 / experiment.py:45-58 on the Seoul-shaped stand-in: embed {TRAIN_CFG['embed']} -> {list(TRAIN_CFG['layers'])}, "
                     f"node dropout {TRAIN_CFG['node_dropout']}, message dropout {list(TRAIN_CFG['mess_dropout'])}, batch {batch}, Adam lr "
                     f"{TRAIN_CFG['lr']}, BPR wd {TRAIN_CFG['wd']}, node_flag=True, train mode; step = forward + BPR + backward + Adam.step; "
@@ -300,6 +303,10 @@ def main_train(args, pkg, dev):
             out["secondary"] = {f"dropout_mode_{other}": train_secondary(pkg, dev, args.batch, other, args.steps, args.warmup)}
         except Exception as exc:  # noqa: BLE001
             out["secondary"] = {f"dropout_mode_{other}": {"error": repr(exc)[:300]}}
+        try:       # the step with device masks captured once and replayed (opt-in GraphedTrainStep; Adam(capturable=True))
+            out["secondary"]["device_masks_hipgraph"] = train_secondary(pkg, dev, args.batch, "device", max(args.steps, 100), 10, graphed=True)
+        except Exception as exc:  # noqa: BLE001
+            out["secondary"]["device_masks_hipgraph"] = {"error": repr(exc)[:300]}
     if not args.no_cpu_baseline:
         N = coo["n_user"] + coo["n_item"]
         L = torch.sparse_coo_tensor(torch.stack([coo["rows"], coo["cols"]]).cpu(), coo["vals"].cpu(), (N, N))
@@ -584,6 +591,10 @@ def main():
                 secondary[f"c1_train_{mode}_masks"] = train_secondary(pkg, dev, args.batch, mode)
             except Exception as exc:  # noqa: BLE001
                 secondary[f"c1_train_{mode}_masks"] = {"error": repr(exc)[:300]}
+        try:
+            secondary["c1_train_device_masks_hipgraph"] = train_secondary(pkg, dev, args.batch, "device", 100, 10, graphed=True)
+        except Exception as exc:  # noqa: BLE001
+            secondary["c1_train_device_masks_hipgraph"] = {"error": repr(exc)[:300]}
         torch.set_grad_enabled(False)
 
     swept = [csr.swept_rows] if world == 1 else sh.swept_rows()

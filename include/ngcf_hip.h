@@ -229,6 +229,15 @@ int ngcf_feature_inject_f32(float *user_w, int64_t ldu, int64_t n_user, int d0,
                             int fw, const int64_t *u_id, int64_t B, double emb_ratio,
                             int32_t *scratch, int32_t *status, void *stream);
 
+/* ---- dropout seeds on the device ---------------------------------------------------------- */
+/* Every 64-bit dropout seed of this interface (drop_seed of the layer entry points, the `seeds` of the node-dropout products) is
+ * either a value below 2^62 or a TAGGED DEVICE ADDRESS: top 16 bits 0xD5ED, low 48 bits the address of a uint64_t that holds the
+ * value - read by the kernels when they run.  A captured hipGraph bakes kernel arguments in; with its seeds behind addresses every
+ * replay still draws new masks.  ngcf_seeds_advance steps n such words to their next values (a splitmix64 chain, results below
+ * 2^62), asynchronously on `stream`. */
+#define NGCF_SEED_PTR_TAG 0xD5EDull
+int ngcf_seeds_advance(uint64_t *seeds_device, int n, void *stream);
+
 /* ---- gathers (NGCF.py:151-155) ---------------------------------------------------------- */
 /* out[b, 0:d] = table[(row_off + idx[b]), 0:d], bit-exact copies.  idx must lie in [0, n_idx_rows);
  * offenders are skipped and *status (device int32) is set non-zero. */

@@ -107,6 +107,7 @@ class NGCF(nn.Module):
         self._graph_seen = set()
         self._plist = None
         self._year_tag, self._year_idx = None, 0
+        self._forced_year_idx = None
 
     # ------------------------------------------------------------------------------------
     # engine plumbing
@@ -302,6 +303,25 @@ class NGCF(nn.Module):
             self._seed_src = src
         return [int(x) for x in torch.randint(0, 2 ** 62, (n,), dtype=torch.int64, generator=self._seed_gen)]
 
+    def _device_seeds(self) -> torch.Tensor:
+        """The 2 n_layer seed words of ONE training forward, as a fresh device tensor.  A persistent state tensor is seeded from
+        the module's private generator (which follows `torch.manual_seed`: the first forward after seeding uses exactly the values
+        `_private_seeds` would hand out) and stepped on the device before every later forward (`ngcf_seeds_advance`); the forward
+        gets a copy of its own, so a backward that runs after another forward still recomputes its own masks.  No host random
+        numbers, no host round trip - and inside a captured hipGraph every replay draws new masks."""
+        dev = self._dev()
+        n = 2 * self.n_layer
+        src = torch.initial_seed()
+        st = getattr(self, "_seed_state", None)
+        if st is None or st.device != dev or st.numel() != n or self._seed_state_src != src:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("device-mode dropout: run one training forward before capturing (the seed state is created on first use)")
+            self._seed_state = torch.tensor(self._private_seeds(n), dtype=torch.int64, device=dev)
+            self._seed_state_src = src
+        else:
+            _eng._lib.check(_eng._lib.load().ngcf_seeds_advance(_eng._ptr(self._seed_state), n, _eng._stream()))
+        return self._seed_state.clone()
+
     # ------------------------------------------------------------------------------------
     # propagation (NGCF.py:120-149)
     # ------------------------------------------------------------------------------------
@@ -321,20 +341,28 @@ class NGCF(nn.Module):
         if node_ref or mess_ref:
             csrs, csrs_t_fn, masks = self._reference_draws(year_idx, node_ref, drop, mess_ref)
         edge_drops = None
+        node_dev = bool(node_flag) and csrs is None                    # node dropout in "device" mode: the cached CSR, thinned in-kernel
         if csrs is None:
             csrs = [self.laplacian_csr(year_idx)] * self.n_layer
             csrs_t_fn = lambda: [self.laplacian_csr_t(year_idx)] * self.n_layer   # noqa: E731
-            if node_flag:
-                # "device" mode: same semantics (cumulative, unscaled), mask = counter-based hash of the entry number
-                # evaluated inside the SpMM kernel; one 64-bit seed per layer
-                ns = self._private_seeds(self.n_layer)
-                edge_drops = [(ns[:k + 1], float(self.node_dropout)) for k in range(self.n_layer)]
+        mess_dev = any(p > 0 for p in drop) and masks is None
         seeds = [0] * self.n_layer
-        if any(p > 0 for p in drop) and masks is None:                 # "device" mode: hash stream in the layer epilogue
-            seeds = self._private_seeds(self.n_layer)
+        keep_alive = None
+        if node_dev or mess_dev:
+            # "device" modes: the seeds of this forward live in device memory and reach the kernels as tagged addresses
+            # (include/ngcf_hip.h, NGCF_SEED_PTR_TAG): words 0..n-1 the node-dropout seeds (layer k uses 0..k: cumulative, unscaled -
+            # the mask is a counter-based hash of (seed, row, column) evaluated inside the SpMM), words n..2n-1 the message-dropout
+            # seeds of the layer epilogues.  The backward recomputes the masks from the same words.
+            keep_alive = self._device_seeds()
+            tag = lambda i: (0xD5ED << 48) | (keep_alive.data_ptr() + 8 * i)   # noqa: E731
+            if node_dev:
+                ns = [tag(k) for k in range(self.n_layer)]
+                edge_drops = [(ns[:k + 1], float(self.node_dropout)) for k in range(self.n_layer)]
+            if mess_dev:
+                seeds = [tag(self.n_layer + k) for k in range(self.n_layer)]
         w1, b1, w2, b2 = self._layer_params()
         all_E = propagate_with_grad(self, csrs, csrs_t_fn, self.user_embedding.weight, self.item_embedding.weight,
-                                    w1, b1, w2, b2, drop, seeds, edge_drops, masks)
+                                    w1, b1, w2, b2, drop, seeds, edge_drops, masks, keep_alive)
         self._all_E = all_E
         self.all_users_emb = all_E[:self.n_user, :]                    # NGCF.py:148-149
         self.all_items_emb = all_E[self.n_user:, :]
@@ -366,6 +394,8 @@ class NGCF(nn.Module):
     def _year_index(self, year: torch.Tensor) -> int:
         """`year.unique()[0] % 18` (NGCF.py:117) = the smallest year of the batch, read back from the device once per tensor:
         the same tensor OBJECT passed again unmodified (same version counter) needs no second host sync."""
+        if self._forced_year_idx is not None:          # GraphedTrainStep: the slice was fixed when the step was captured
+            return self._forced_year_idx
         if not year.numel():
             return 0
         ref, ver = self._year_tag if self._year_tag is not None else (None, -1)
@@ -453,7 +483,7 @@ class NGCF(nn.Module):
                 self._all_E, ((u_idx, 0, self.n_user), (p_idx, self.n_user, self.n_item), (n_idx, self.n_user, self.n_item)), status)
             if neg is not None:
                 neg_i_embeddings = neg
-        if self.check_indices:
+        if self.check_indices and not torch.cuda.is_current_stream_capturing():   # (a captured step checks the sticky word after its replay)
             if int(status.item()) != 0:
                 status.zero_()
                 raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")

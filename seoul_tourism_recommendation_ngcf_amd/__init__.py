@@ -6,7 +6,7 @@ Drop-in for the hot path of haesungpyun/seoul_tourism_recommendation_NGCF:
 """
 from .NGCF import NGCF
 from .bprloss import BPR
-from .graphed import GraphedForward
+from .graphed import GraphedForward, GraphedTrainStep
 from . import engine, graphs
 
-__all__ = ["NGCF", "BPR", "GraphedForward", "engine", "graphs"]
+__all__ = ["NGCF", "BPR", "GraphedForward", "GraphedTrainStep", "engine", "graphs"]

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "ngcf_copy_rows2_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_feature_inject_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_i64), C.c_int, _vp, _i64, C.c_double, _vp, _vp, _vp]),
+    "ngcf_seeds_advance": (C.c_int, [_vp, C.c_int, _vp]),
     "ngcf_gather_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "ngcf_gather_rows3_f32": (C.c_int, [_vp, _i64, C.c_int] + [_vp, _i64, _i64, _i64, _vp] * 3 + [_i64, _vp, _vp]),
     "ngcf_bpr_workspace_bytes": (_i64, [_i64]),

@@ -162,6 +162,7 @@ class Propagate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, csrs, csrs_t, drop, seeds, edge_drops, masks, n_layer, user_w, item_w, *params):
+        seeds, ctx.seed_words = seeds if isinstance(seeds, tuple) else (seeds, None)
         w1, b1 = params[:n_layer], params[n_layer:2 * n_layer]
         w2, b2 = params[2 * n_layer:3 * n_layer], params[3 * n_layer:]
         dev = user_w.device
@@ -347,12 +348,13 @@ class BPRLoss(torch.autograd.Function):
 
 
 def propagate_with_grad(owner, csrs, csrs_t_fn, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops=None,
-                        masks=None) -> torch.Tensor:
+                        masks=None, keep_alive=None) -> torch.Tensor:
     """Inference path unless a gradient can flow; then the autograd Function (needs the CSRs of L^T)."""
     params = list(w1) + list(b1) + list(w2) + list(b2)
     need = torch.is_grad_enabled() and any(t.requires_grad for t in [user_w, item_w] + params)
     if not need:
         with torch.no_grad():
             return propagate_forward(owner, csrs, user_w, item_w, w1, b1, w2, b2, drop, seeds, edge_drops, masks)
-    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), list(seeds), edge_drops, masks, len(w1), user_w, item_w,
+    # (`keep_alive`: the device words behind tagged seeds - stored on the ctx so that they live as long as the backward can run)
+    return Propagate.apply(owner, csrs, csrs_t_fn(), list(drop), (list(seeds), keep_alive), edge_drops, masks, len(w1), user_w, item_w,
                            *params)

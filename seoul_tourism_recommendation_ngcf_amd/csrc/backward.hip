@@ -113,11 +113,12 @@ extern "C" int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, con
 __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restrict__ dN, int64_t ldn,
                                                             const float *__restrict__ dC, int64_t ldc,
                                                             const float *__restrict__ C, int64_t ldC, int64_t n_rows,
-                                                            int d, float leaky, float drop_p, uint64_t seed,
+                                                            int d, float leaky, float drop_p, uint64_t seed_in,
                                                             const float *__restrict__ drop_mask, int64_t ldk,
                                                             const int64_t *__restrict__ row_ids,
                                                             float *__restrict__ dM, int64_t ldm)
 {
+    const uint64_t seed = drop_p > 0.f ? resolve_seed(seed_in) : seed_in;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const int64_t r_hash = row_ids ? row_ids[r] : r;         // compacted rows: the hash stream is indexed by the row of the matrix
@@ -558,8 +559,9 @@ __global__ __launch_bounds__(256) void spmm_t_rows_kernel(const int64_t *__restr
                                                           int64_t n_seg, int64_t seg_blocks, int seg_len,
                                                           const int32_t *__restrict__ slot, const float *__restrict__ X, int64_t ldx, int d,
                                                           const float *__restrict__ init, int64_t ldi, float *__restrict__ out, int64_t ldo,
-                                                          float *__restrict__ partial, int dp, EdgeDrop dr)
+                                                          float *__restrict__ partial, int dp, EdgeDrop dr_in)
 {
+    const EdgeDrop dr = dr_in.n > 0 ? resolve_drop(dr_in) : dr_in;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t begin, end, row;
     float *dst;

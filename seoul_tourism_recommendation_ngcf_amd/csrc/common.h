@@ -220,12 +220,29 @@ __device__ inline uint32_t mix32(uint64_t x)
 // The key is the entry's (row, column) in L - not its position in some storage order - so every kernel that walks L in
 // whatever layout (row-wise CSR, the L2-swept plan, the rows of L^T, a scatter over selected rows) thins it the same way
 // without a map between layouts; `transposed` says that the CSR being walked is L^T (its rows are L's columns).
+// A 64-bit dropout seed is either a value or - top 16 bits == kSeedPtrTag - the device address (low 48 bits) of a uint64_t that
+// holds the value: a captured hipGraph bakes its kernel arguments in, and with the seeds behind a pointer every replay still draws
+// new masks (the mirror advances the words on the device).  Values handed over by the mirror are below 2^62, so they never
+// carry the tag.  Kernels resolve a seed ONCE, at their start.
+constexpr uint64_t kSeedPtrTag = 0xD5EDull;
+__device__ inline uint64_t resolve_seed(uint64_t s)
+{
+    return (s >> 48) == kSeedPtrTag ? *reinterpret_cast<const uint64_t *>(s & 0xFFFFFFFFFFFFull) : s;
+}
+
 struct EdgeDrop {
     int n;                  // number of seeds (0 = no dropout)
     uint32_t thr;           // p * 2^32
     uint64_t seed[4];
     int transposed;
 };
+
+__device__ inline EdgeDrop resolve_drop(EdgeDrop dr)       // at kernel start: seeds given as tagged device addresses -> values
+{
+    for (int q = 0; q < 4; ++q)
+        if (q < dr.n) dr.seed[q] = resolve_seed(dr.seed[q]);
+    return dr;
+}
 
 __device__ inline bool edge_keep(const EdgeDrop &dr, int64_t row, int64_t col)   // row, col of the CSR being walked
 {

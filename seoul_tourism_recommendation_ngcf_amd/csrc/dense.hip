@@ -60,11 +60,12 @@ __global__ __launch_bounds__(256, NGCF_DENSE_WAVES_PER_EU) void layer_dense_kern
                                                           const float *__restrict__ Es, int64_t ldE, int64_t n_rows,
                                                           int d_in, int d_out, const float *__restrict__ Wt,
                                                           const float *__restrict__ bias2, int n_chunks,
-                                                          float leaky, float drop_p, uint64_t drop_seed,
+                                                          float leaky, float drop_p, uint64_t drop_seed_in,
                                                           const float *__restrict__ drop_mask, int64_t ldm,
                                                           float *__restrict__ carry, int64_t ldc,
                                                           float *__restrict__ norm, int64_t ldn)
 {
+    const uint64_t drop_seed = drop_p > 0.f ? resolve_seed(drop_seed_in) : drop_seed_in;
     constexpr int BM = 32 * RW;
     constexpr int WCOLS = 32 * NT * CW;      // == DOP
     constexpr int XLD = NGCF_KC + 4;         // 36: rows stay 16-B aligned and b128 column reads are conflict-free
@@ -339,9 +340,10 @@ constexpr int kResWaves = 8, kResWGs = 256;
 
 __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
     const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ Es, int64_t ldE, int64_t n_rows, int d_in, int d_out,
-    const float *__restrict__ Wt, const float *__restrict__ bias2, int n_chunks, float leaky, float drop_p, uint64_t drop_seed,
+    const float *__restrict__ Wt, const float *__restrict__ bias2, int n_chunks, float leaky, float drop_p, uint64_t drop_seed_in,
     const float *__restrict__ drop_mask, int64_t ldm, float *__restrict__ carry, int64_t ldc, float *__restrict__ norm, int64_t ldn)
 {
+    const uint64_t drop_seed = drop_p > 0.f ? resolve_seed(drop_seed_in) : drop_seed_in;
     constexpr int NT = 4, WCOLS = 128;
     extern __shared__ float Wres[];                 // [n_chunks * 32][128], the layout of pack_weights_kernel
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -555,9 +557,10 @@ template <> struct TileVec<2> { using type = f32x2; };
 template <int CW, int NT>
 __global__ __launch_bounds__(CW * 64) void layer_dense_direct_kernel(
     const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ Es, int64_t ldE, int64_t n_rows, int d_in, int d_out,
-    const float *__restrict__ Wt, const float *__restrict__ bias2, int n_chunks, float leaky, float drop_p, uint64_t drop_seed,
+    const float *__restrict__ Wt, const float *__restrict__ bias2, int n_chunks, float leaky, float drop_p, uint64_t drop_seed_in,
     const float *__restrict__ drop_mask, int64_t ldm, float *__restrict__ carry, int64_t ldc, float *__restrict__ norm, int64_t ldn)
 {
+    const uint64_t drop_seed = drop_p > 0.f ? resolve_seed(drop_seed_in) : drop_seed_in;
     constexpr int WCOLS = 32 * NT * CW;            // weights packed with this NT: a lane's NT tile values are contiguous
     using BV = typename TileVec<NT>::type;
     __shared__ float ssq[32 * CW];

@@ -620,3 +620,29 @@ extern "C" int ngcf_recommend_topk_f32(const float *u, int64_t ldu, int64_t B, c
     LAUNCH_CHECK();
     return NGCF_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Dropout seeds that live on the device (common.h, resolve_seed): every word steps to the next value of a counter-based chain.
+// Launched by the mirror at the start of a training forward in "device" dropout mode - inside a captured hipGraph too, so that
+// every replay draws new masks although its kernel arguments are baked in.
+// ---------------------------------------------------------------------------------------------
+__global__ void seeds_advance_kernel(uint64_t *seeds, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = seeds[i] + 0x9E3779B97F4A7C15ULL;          // splitmix64 step
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    seeds[i] = x >> 2;                                      // below 2^62: a value never looks like a tagged address
+}
+
+extern "C" int ngcf_seeds_advance(uint64_t *seeds, int n, void *stream)
+{
+    if (n <= 0) return NGCF_OK;
+    if (!seeds) return fail(NGCF_ERR_ARG, "seeds_advance: null argument");
+    seeds_advance_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(seeds, n);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}

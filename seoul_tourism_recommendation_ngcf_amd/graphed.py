@@ -136,3 +136,92 @@ class GraphedForward:
         if int(self.status.item()) != 0:
             self.status.zero_()
             raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
+
+
+
+class GraphedTrainStep:
+    """One training step of experiment.py:45-58 - `model(node_flag=...)` -> `optimizer.zero_grad()` -> BPR -> `loss.backward()` ->
+    `optimizer.step()` - captured into ONE hipGraph and replayed per batch.  On the Seoul-sized graph the step is ~70 launches of a
+    few microseconds; replayed, the host issues one graph launch and the step runs at its kernel time.
+
+    Opt-in (the optimizer is the caller's and must be built with `capturable=True`), for launch-bound sizes (all_E up to
+    `autograd.DENSE_GRAD_MAX_BYTES`: the backward then has no host sync), dropout in "device" mode (the seeds live in device memory
+    and are stepped inside the graph: every replay draws new masks).  Constructing it runs `warmup` REAL training steps on
+    `first_batch` (they count as training, like the warm-up of torch's whole-network capture recipe) and then captures.  A replay
+    is bit-identical to the eager step it replaces."""
+
+    KEYS = ("year", "u_id", "age", "sex", "month", "day", "dow", "pos_item", "neg_item")
+
+    def __init__(self, model, criterion, optimizer, first_batch: dict, node_flag: bool = True, warmup: int = 3):
+        from . import autograd as _ag
+        if not model.training:
+            raise RuntimeError("GraphedTrainStep captures the training step: call model.train() first")
+        if model.node_dropout_mode != "device" or model.mess_dropout_mode != "device":
+            raise RuntimeError("GraphedTrainStep needs node_dropout_mode = mess_dropout_mode = 'device' (the reference modes draw their "
+                               "masks on the host every step)")
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise RuntimeError("GraphedTrainStep: build the optimizer with capturable=True (torch keeps its step counters on the device then)")
+        dev = model._dev()
+        N, D = model.n_user + model.n_item, model.emb_size + sum(model.weight_size)
+        if N * D * 4 > _ag.DENSE_GRAD_MAX_BYTES:
+            raise RuntimeError("GraphedTrainStep is for launch-bound sizes: the backward of a larger graph reads the number of gathered "
+                               "rows back to the host (a step of that size is not launch-bound anyway)")
+        self.model, self.criterion, self.optimizer, self.node_flag, self.dev = model, criterion, optimizer, bool(node_flag), dev
+        self.inputs = {k: first_batch[k].to(device=dev, dtype=torch.int64).clone() for k in self.KEYS}
+        self.year_idx = int(self.inputs["year"].min().item() % 18) if self.inputs["year"].numel() else 0
+        self.status = model._status_buf(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        model._forced_year_idx = self.year_idx
+        try:
+            with torch.cuda.stream(side):                    # warm-up: every cached buffer, plan and optimizer state exists before the capture
+                for _ in range(max(int(warmup), 1)):
+                    self._body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._body()
+        finally:
+            model._forced_year_idx = None
+        torch.cuda.synchronize(dev)
+        self._baked = self._baked_pointers()
+        self.steps_done = max(int(warmup), 1)                # real steps taken on first_batch so far (the capture itself runs nothing)
+
+    def _body(self):
+        m = self.model
+        u, p, n = m(node_flag=self.node_flag, **self.inputs)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.criterion(u, p, n)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def _baked_pointers(self):
+        m = self.model
+        return tuple(t.data_ptr() for t in ([m._ws.buf, self.criterion._ws.buf, getattr(m, "_seed_state", None), self.status] + list(m.parameters()))
+                     if t is not None)
+
+    def __call__(self, **batch):
+        """One training step on `batch` (the nine keyword tensors of NGCF.forward, lengths as captured); returns the loss (a 0-dim
+        tensor owned by the graph: valid until the next call)."""
+        vals = []
+        for k in self.KEYS:
+            v = batch[k]
+            if int(v.numel()) != int(self.inputs[k].numel()):
+                raise RuntimeError(f"GraphedTrainStep was captured for {self.inputs[k].numel()} elements of {k}: got {int(v.numel())}")
+            vals.append(v)
+        if all(v.dtype == torch.int64 and v.device == self.dev and v.dim() == 1 for v in vals):
+            torch._foreach_copy_([self.inputs[k] for k in self.KEYS], vals)
+        else:
+            for k, v in zip(self.KEYS, vals):
+                self.inputs[k].copy_(v.reshape(-1), non_blocking=True)
+        if self._baked_pointers() != self._baked:
+            raise RuntimeError("GraphedTrainStep: a buffer or parameter baked into the captured step was replaced; capture again")
+        self.graph.replay()
+        self.steps_done += 1
+        m = self.model
+        if m.check_indices and self.steps_done % max(1, int(m.index_check_every)) == 0 and int(self.status.item()) != 0:
+            self.status.zero_()
+            raise IndexError("index out of range in a graph-replayed training step (u_id / feature ids / pos_item / neg_item)")
+        return self.loss

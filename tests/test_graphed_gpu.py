@@ -162,3 +162,48 @@ def test_unchanged_callers_get_the_graph_replay(dev):
     auto.check_indices_now()                                           # the status word was reset by the raise
     plain.user_embedding.weight.data.copy_(auto.user_embedding.weight.data)
     same(eval_batch())
+
+
+def test_graphed_train_step_replays_the_eager_step(dev):
+    """GraphedTrainStep (forward with node + message dropout in device mode, BPR, backward, Adam) against the same steps issued
+    eagerly: same seed, same batches -> the same losses and the same parameters bit for bit, step after step (the dropout seeds live
+    in device memory and are stepped inside the graph, so every replay draws the masks the eager step would)."""
+    pkg = _pkg()
+    slices = pkg.graphs.seoul_standin(dev, seed=5, n_user=700, n_item=40)
+    lap = [pkg.graphs.to_sparse_coo(s) for s in slices]
+    U, I, B = 700, 40, 128
+    num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    g = torch.Generator().manual_seed(21)
+    batches = [_batch(g, B, U, I, dev) for _ in range(7)]
+    for b in batches:
+        b["u_id"][:9] = b["u_id"][9:18]                               # duplicates in every batch
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(3)
+        model = pkg.NGCF(65, [65, 65, 65], 0.3, [0.1, 0.1, 0.1], 1.0, lap, num_dict, B, dev).to(dev)
+        model.train()
+        model.node_dropout_mode = model.mess_dropout_mode = "device"
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+        crit = pkg.BPR(0.025, B)
+        torch.manual_seed(11)                                          # the module's seed chain follows torch.manual_seed
+        losses = []
+        if graphed:
+            step = pkg.GraphedTrainStep(model, crit, opt, batches[0], node_flag=True, warmup=3)
+            for b in batches[1:]:
+                losses.append(float(step(**b)))
+        else:
+            for b in [batches[0]] * 3 + batches[1:]:
+                u, p, n = model(node_flag=True, **b)
+                opt.zero_grad()
+                loss = crit(u, p, n)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            losses = losses[3:]
+        results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    assert len(set(results[0][0])) > 1                                 # the losses move: new masks and new parameters every step
+    for k in results[0][1]:
+        assert torch.equal(results[0][1][k], results[1][1][k]), k
+    with pytest.raises(RuntimeError, match="capturable"):
+        pkg.GraphedTrainStep(model, crit, torch.optim.Adam(model.parameters(), lr=1e-2), batches[0])
