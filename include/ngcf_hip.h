@@ -43,7 +43,7 @@ const char *ngcf_last_error(void);
 const char *ngcf_target_arch(void);
 /* ABI version of this header.  ngcf_version() returns the value the library was built with; the Python mirror refuses to bind
  * a library whose version differs (a stale .so would otherwise receive shifted arguments). */
-#define NGCF_ABI_VERSION 4
+#define NGCF_ABI_VERSION 5
 int ngcf_version(void);
 
 /* Tunables of the kernel dispatch (thresholds, lab switches).  The library reads its NGCF_* environment variables ONCE, in
@@ -284,8 +284,9 @@ int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t 
  * order int64[M] (the positions 0..M-1 sorted by row, equal rows in batch order), rows int64[<= M] (distinct, ascending),
  * segptr int64[<= M + 1] (group bounds inside `order`), n_rows int64[1].  All device arrays sized for M (segptr M + 1).
  * Feeds ngcf_segment_sum_rows_f32; replaces torch.unique + sort + cumsum (a dozen library launches) on the training step. */
-int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t *order, int64_t *rows, int64_t *segptr, int64_t *n_rows,
-                          void *stream);
+int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t max_row, int64_t *order, int64_t *rows, int64_t *segptr,
+                          int64_t *n_rows, void *stream);
+/* (max_row: an upper bound of the values in idx, or -1 = unknown: below 2^19 the sort runs on 32-bit keys) */
 /* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block; NULL = zero:
  * the rows no gather touched), dC (gradient of the carry from the next layer, may be NULL; not both) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,

@@ -301,7 +301,7 @@ class GatherTriple(torch.autograd.Function):
             order, rows, segptr, cnt = buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:]
             G = torch.zeros((N, D), dtype=torch.float32, device=dev)
             with _eng._on(dev):
-                _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
+                _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, N - 1, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
                 _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), M, _ptr(rows), _ptr(cnt), _ptr(G), D,
                                                          _stream()))
             return (G, None, None, None, None, None)
@@ -310,7 +310,7 @@ class GatherTriple(torch.autograd.Function):
             buf = torch.empty(3 * M + 2, dtype=torch.int64, device=dev)
             order, rows, segptr, cnt = buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:]
             with _eng._on(dev):
-                _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
+                _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, N - 1, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
             R = int(cnt.item())                                    # (the one host sync of the backward: sizes the compacted problem)
             rows, segptr = rows[:R], segptr[:R + 1]
         else:

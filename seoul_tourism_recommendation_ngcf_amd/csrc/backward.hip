@@ -285,13 +285,18 @@ __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict
         if (more) store_block(buf ^ 1);
         __syncthreads();
     }
-    float *out = partial + (int64_t)blockIdx.x * kBwM * kBwN;
+    // the partial leaves COMPACT: [d_out][2 d_in] contiguous per workgroup (r03: the padded [128][256] tile made the reduction
+    // read a 4-byte word out of every 128 KB per workgroup and output element)
+    float *out = partial + (int64_t)blockIdx.x * d_out * 2 * d_in;
+    const int col = wave * 32 + li;                       // column of the [P | P] operand: sums in [0, P), products in [P, 2 P)
+    const int cc = col < P ? col : d_in + (col - P);      // its place in [d_in | d_in]
+    const bool col_ok = col < P ? col < d_in : (col - P) < d_in;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[o * kBwN + wave * 32 + li] = acc[t][r];
+            if (col_ok && o < d_out) out[o * 2 * d_in + cc] = acc[t][r];
         }
     // the four row-quarters of a column, added in a fixed order (the last loop iteration ended with a barrier: As is free)
     float *bs = &As[0][0][0];
@@ -316,20 +321,23 @@ __global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, cons
         return;
     }
     const int o = i / (2 * d_in), c = i % (2 * d_in);
-    const int src = c < d_in ? c : P + (c - d_in);
-    // four independent chains (workgroups w = q mod 4), combined in a fixed order: the loads of a chain do not wait for each other
-    const float *p = partial + (int64_t)o * kBwN + src;
-    const int64_t step = (int64_t)kBwM * kBwN;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // eight independent chains (workgroups w = q mod 8), combined in a fixed order: the loads of a chain do not wait for each other
+    const float *p = partial + i;
+    const int64_t step = (int64_t)d_out * 2 * d_in;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     int w = 0;
-    for (; w + 4 <= n_wg; w += 4) {
+    for (; w + 8 <= n_wg; w += 8) {
         s0 += p[(w + 0) * step];
         s1 += p[(w + 1) * step];
         s2 += p[(w + 2) * step];
         s3 += p[(w + 3) * step];
+        s4 += p[(w + 4) * step];
+        s5 += p[(w + 5) * step];
+        s6 += p[(w + 6) * step];
+        s7 += p[(w + 7) * step];
     }
     for (; w < n_wg; ++w) s0 += p[w * step];
-    const float r = (s0 + s1) + (s2 + s3);
+    const float r = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     if (c < d_in) gW1[(int64_t)o * ld1 + c] = r;
     else gW2[(int64_t)o * ld2 + (c - d_in)] = r;
 }
@@ -357,10 +365,10 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
     const int P = (int)align_up(d_in, 32);
     const bool al = ldM % 4 == 0 && ldLE % 4 == 0 && ldE % 4 == 0 && aligned16(dM) && aligned16(LE) && aligned16(E);
     // workgroups: one per CU on a large matrix; on a small one (the Seoul graph's 5 940 rows are 186 blocks, a compacted last
-    // layer a few dozen) every workgroup should still see >= 4 blocks - each writes a 128 KB partial that the reduction reads
+    // layer a few dozen) every workgroup should still see >= 2 blocks - each writes a 128 KB partial that the reduction reads
     // back (256 of them: 33 MB and 116 us for a 65 x 130 gradient)
     const int64_t n_blocks = (n_rows + kBwRows - 1) / kBwRows;
-    const int n_wg = (int)std::min<int64_t>(kBwWGs, std::max<int64_t>(1, (n_blocks + 3) / 4));
+    const int n_wg = (int)std::min<int64_t>(kBwWGs, std::max<int64_t>(1, (n_blocks + 1) / 2));
     if (al)
         bwd_weight_kernel<true><<<n_wg, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     else
@@ -402,26 +410,34 @@ __global__ void bwd_input_pack_kernel(const float *__restrict__ W1, const float 
 
 // NT 32x32 tiles per wave: a panel of 32*NT input columns (NT = 4: 128; NT = 5: 160, which takes the reference's 130-wide
 // first layer in one panel instead of two)
-template <int NT>
+// SMALL (r03): a workgroup owns 32 rows and its four waves split the panel's columns (one 32x32 tile each at NT = 4) instead of
+// 128 rows with a wave per 32 of them: on a matrix of a few thousand rows (the Seoul graph's 5 940: 47 workgroups of the tall shape
+// on 256 CUs, 34 us) the panel is spread over 186 workgroups.
+template <int NT, bool SMALL>
 __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__restrict__ dM, int64_t ldM, int64_t n_rows, int d_out,
                                                               const float *__restrict__ Wp, int n_chunks,
                                                               const float *__restrict__ LE, int64_t ldLE,
                                                               const float *__restrict__ E, int64_t ldE, int d_in, int col0,
                                                               float *__restrict__ dLE, int64_t ldd, float *__restrict__ dE, int64_t lde)
 {
-    constexpr int BM = kBiRows, WCOLS = 32 * NT, XLD = NGCF_BI_KC + 4;
+    constexpr int BM = SMALL ? 32 : kBiRows, WCOLS = 32 * NT, XLD = NGCF_BI_KC + 4;
+    constexpr int NTW = SMALL ? NT / 4 : NT;          // tiles per wave
+    constexpr int XJ = BM * 8 / 256;                  // float4 of a dM chunk per thread
+    static_assert(!SMALL || NT % 4 == 0, "the small shape splits the panel's tiles over four waves");
     __shared__ float Xs[2 * BM * XLD];
     __shared__ float Ws[2 * NGCF_BI_KC * WCOLS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int d4 = (d_out + 3) & ~3;
-    bw_f32x16 acc[2][NT];
-    bw_f32x4 xreg[4], wreg[NT];
+    bw_f32x16 acc[2][NTW];
+    bw_f32x4 xreg[XJ], wreg[NT];
+    const int tile0 = SMALL ? wave * NTW : 0;         // first tile (32 columns) of this wave
+    const int wrow = SMALL ? 0 : wave * 32;           // first row of this wave inside the workgroup's rows
 
     auto load_chunk = [&](int half, int chunk) {      // global -> registers (rows past the end re-read the last row, never stored)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < XJ; ++j) {
             const int f = tid + 256 * j;
             int64_t grow = row0 + f / 8;
             grow = grow < n_rows ? grow : n_rows - 1;
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < XJ; ++j) {
             const int f = tid + 256 * j;
             *reinterpret_cast<bw_f32x4 *>(Xs + buf * (BM * XLD) + (f / 8) * XLD + (f % 8) * 4) = xreg[j];
         }
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[half][t][r] = 0.f;
         load_chunk(half, 0);
@@ -461,8 +477,8 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__
             const bool more = chunk + 1 < n_chunks;
             if (more) load_chunk(half, chunk + 1);      // global loads fly under the MFMAs
             const int buf = chunk & 1;
-            const float *X = Xs + buf * (BM * XLD) + (wave * 32 + li) * XLD + lh * 4;
-            const float *W = Ws + buf * (NGCF_BI_KC * WCOLS) + li;
+            const float *X = Xs + buf * (BM * XLD) + (wrow + li) * XLD + lh * 4;
+            const float *W = Ws + buf * (NGCF_BI_KC * WCOLS) + tile0 * 32 + li;
 #pragma unroll
             for (int kb = 0; kb < NGCF_BI_KC / 8; ++kb) {
                 const bw_f32x4 a4 = *reinterpret_cast<const bw_f32x4 *>(X + kb * 8);
@@ -470,11 +486,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__
 #pragma unroll
                 for (int sx = 0; sx < 4; ++sx) {
                     const float *wk = W + (kb * 8 + lh * 4 + sx) * WCOLS;
-                    float bv[NT];
+                    float bv[NTW];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) bv[t] = wk[t * 32];
+                    for (int t = 0; t < NTW; ++t) bv[t] = wk[t * 32];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[half][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], bv[t], acc[half][t], 0, 0, 0);
+                    for (int t = 0; t < NTW; ++t) acc[half][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], bv[t], acc[half][t], 0, 0, 0);
                 }
             }
             if (more) store_chunk((chunk + 1) & 1);
@@ -484,11 +500,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__
     // epilogue: dLE = dS + dP * E, dE = dS + dP * LE
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t grow = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int64_t grow = row0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (grow >= n_rows) continue;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = col0 + t * 32 + li;
+        for (int t = 0; t < NTW; ++t) {
+            const int col = col0 + (tile0 + t) * 32 + li;
             if (col < d_in) {
                 const float ds = acc[0][t][r], dp = acc[1][t][r];
                 dLE[grow * ldd + col] = fmaf(dp, E[grow * ldE + col], ds);
@@ -529,11 +545,14 @@ extern "C" int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_
         bwd_input_pack_kernel<<<64, 256, 0, stream>>>(W1, W2, d_out, d_in, col0, wcols, n_chunks, Wp);
         LAUNCH_CHECK();
         if (wcols == 160)
-            layer_bwd_input_kernel<5><<<dim3((unsigned)blocks), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE, E, ldE,
-                                                                                  d_in, col0, dLE, ldd, dE, lde);
+            layer_bwd_input_kernel<5, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE, E, ldE,
+                                                                                         d_in, col0, dLE, ldd, dE, lde);
+        else if (n_rows <= 16384)         // fewer than 128 tall tiles: 32-row tiles, the waves side by side (see the kernel)
+            layer_bwd_input_kernel<4, true><<<dim3((unsigned)((n_rows + 31) / 32)), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE,
+                                                                                                    E, ldE, d_in, col0, dLE, ldd, dE, lde);
         else
-            layer_bwd_input_kernel<4><<<dim3((unsigned)blocks), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE, E, ldE,
-                                                                                  d_in, col0, dLE, ldd, dE, lde);
+            layer_bwd_input_kernel<4, false><<<dim3((unsigned)blocks), 256, 0, stream>>>(dM, ldM, n_rows, d_out, Wp, n_chunks, LE, ldLE, E, ldE,
+                                                                                         d_in, col0, dLE, ldd, dE, lde);
         LAUNCH_CHECK();
         col0 += wcols;
     }
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(256) void spmm_t_rows_kernel(const int64_t *__restr
                                                           const float *__restrict__ init, int64_t ldi, float *__restrict__ out, int64_t ldo,
                                                           float *__restrict__ partial, int dp, EdgeDrop dr_in)
 {
-    const EdgeDrop dr = dr_in.n > 0 ? resolve_drop(dr_in) : dr_in;
+    const EdgeDropR dr = resolve_drop(dr_in);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t begin, end, row;
     float *dst;
@@ -672,25 +691,26 @@ extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, co
 // =============================================================================================
 static constexpr int kSortMax = 8192, kSortThreads = 1024;
 
+template <typename K>     // key type: 32 bits when row << 13 | position fits (rows below 2^19: the Seoul graph), else 64
 __global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const int64_t *__restrict__ idx, int M, int64_t *__restrict__ order,
                                                                         int64_t *__restrict__ rows, int64_t *__restrict__ segptr,
                                                                         int64_t *__restrict__ n_rows)
 {
-    __shared__ unsigned long long key[kSortMax];
+    __shared__ K key[kSortMax];
     __shared__ int wsum[kSortThreads / 64];
     __shared__ int carry_s;
     const int tid = threadIdx.x;
     int P = 64;
     while (P < M) P <<= 1;                                          // power of two >= M
     for (int i = tid; i < P; i += kSortThreads)
-        key[i] = i < M ? ((unsigned long long)idx[i] << 13) | (unsigned)i : ~0ull;
+        key[i] = i < M ? (K)(((K)idx[i] << 13) | (K)i) : (K)~(K)0;
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < P; i += kSortThreads) {
                 const int l = i ^ j;
                 if (l > i) {
-                    const unsigned long long a = key[i], b = key[l];
+                    const K a = key[i], b = key[l];
                     const bool up = (i & k) == 0;
                     if ((a > b) == up) {
                         key[i] = b;
@@ -707,7 +727,7 @@ __global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const in
     for (int base = 0; base < M; base += kSortThreads) {
         const int i = base + tid;
         int head = 0;
-        unsigned long long kv = 0;
+        K kv = 0;
         if (i < M) {
             kv = key[i];
             order[i] = (int64_t)(kv & 8191u);
@@ -738,12 +758,15 @@ __global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const in
     }
 }
 
-extern "C" int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t *order, int64_t *rows, int64_t *segptr, int64_t *n_rows,
-                                     void *stream)
+extern "C" int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t max_row, int64_t *order, int64_t *rows, int64_t *segptr,
+                                     int64_t *n_rows, void *stream)
 {
     if (M < 0 || M > kSortMax) return fail(NGCF_ERR_ARG, "rows_sort_unique: M=%lld not in [0, %d]", (long long)M, kSortMax);
     if (!order || !rows || !segptr || !n_rows || (M > 0 && !idx)) return fail(NGCF_ERR_ARG, "rows_sort_unique: null argument");
-    rows_sort_unique_kernel<<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, order, rows, segptr, n_rows);
+    if (max_row >= 0 && max_row < ((int64_t)1 << 19) - 1)
+        rows_sort_unique_kernel<unsigned><<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, order, rows, segptr, n_rows);
+    else
+        rows_sort_unique_kernel<unsigned long long><<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, order, rows, segptr, n_rows);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int64_t *__restrict__ r
                                                    float *__restrict__ partial, int dp, EdgeDrop dr_in)
 {
     using V = typename VecT<VEC>::type;
-    const EdgeDrop dr = dr_in.n > 0 ? resolve_drop(dr_in) : dr_in;
+    const EdgeDropR dr = resolve_drop(dr_in);
     const int wave = threadIdx.x >> 6;
     int64_t begin, end, row;
     float *dst;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void spmm_sliced_kernel(const int64_t *__restr
                                                           const float *__restrict__ E, int64_t ldE,
                                                           float *__restrict__ out, int64_t ldo, EdgeDrop dr_in)
 {
-    const EdgeDrop dr = dr_in.n > 0 ? resolve_drop(dr_in) : dr_in;
+    const EdgeDropR dr = resolve_drop(dr_in);
     const int64_t slice = blockIdx.x / row_blocks;
     const int64_t row = row_begin + ((int64_t)blockIdx.x % row_blocks) * 4 + (threadIdx.x >> 6);
     if (row >= row_end) return;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kLdsTabWaves * 64) void spmm_ldstab_kernel(const in
                                                           int d, int col_lo, int n_tab, float *__restrict__ out, int64_t ldo,
                                                           EdgeDrop dr_in)
 {
-    const EdgeDrop dr = dr_in.n > 0 ? resolve_drop(dr_in) : dr_in;
+    const EdgeDropR dr = resolve_drop(dr_in);
     extern __shared__ float4 tab4[];               // [n_tab + 1][16]: one 64-float slice of table rows col_lo .. col_lo + n_tab - 1, then a row of zeros
     const int slice = blockIdx.y;
     const int w = d - slice * 64 < 64 ? d - slice * 64 : 64;      // width of this slice (a multiple of 4)

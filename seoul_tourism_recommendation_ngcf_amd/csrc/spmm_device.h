@@ -75,7 +75,7 @@ __device__ inline void spmm_combine(typename VecT<VEC>::type (&acc)[CH])
 template <int VEC, int LPR, int CH, int U>
 __device__ inline void spmm_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
                                        int64_t begin, int64_t end, const float *__restrict__ E, int64_t ldE,
-                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDrop &dr = EdgeDrop{0, 0, {0, 0, 0, 0}, 0},
+                                       int d, typename VecT<VEC>::type (&acc)[CH], const EdgeDropR &dr = EdgeDropR{0, 0, 0, 0, 0, 0, 0},
                                        int pad_col = 0, int64_t row = 0)     // row: the CSR row being walked (edge dropout key)
 {
     const int lane = threadIdx.x & 63;

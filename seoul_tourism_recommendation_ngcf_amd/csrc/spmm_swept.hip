@@ -585,7 +585,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_swept_kernel(SweptLaunch L, int 
                                                              int max_spin, int sync_k, unsigned prio_cols, int prio_graded, int nt_flags,
                                                              unsigned long long *__restrict__ dbg, EdgeDrop dr_in)
 {
-    const EdgeDrop dr = DROP ? resolve_drop(dr_in) : dr_in;
+    const EdgeDropR dr = resolve_drop(dr_in);
     constexpr int kSW = LPE * 4, kEPR = 64 / LPE, kCH = 16 * kEPR;
     __shared__ float acc_lds[NW * (RW + 1) * kSW];   // per wave: RW accumulator rows + the spare row of the empty slots
     __shared__ unsigned wg_cnt[kRing];

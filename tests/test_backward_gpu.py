@@ -365,7 +365,7 @@ def test_rows_sort_unique_kernel_vs_torch_unique(M, N, dev):
     buf = torch.full((3 * M + 2,), -7, dtype=torch.int64, device=dev)
     order, rows, segptr, cnt = buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:]
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(lib.ngcf_rows_sort_unique(p(idx), M, p(order), p(rows), p(segptr), p(cnt), None))
+    _lib.check(lib.ngcf_rows_sort_unique(p(idx), M, N - 1, p(order), p(rows), p(segptr), p(cnt), None))     # N < 2^19: 32-bit keys
     torch.cuda.synchronize()
     want_rows, inv, counts = torch.unique(idx, return_inverse=True, return_counts=True)
     R = int(cnt.item())

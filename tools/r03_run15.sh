@@ -1,0 +1,13 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export NGCF_NO_BUILD=1
+mkdir -p gpurun_out/r03
+timeout -k 10 600 python -m pytest tests/test_backward_gpu.py tests/test_graphed_gpu.py tests/test_node_dropout_device_gpu.py -m gpu -x -q > gpurun_out/r03/gputests15.log 2>&1
+timeout -k 10 200 python bench.py --workload c1_train --dropout-mode device > gpurun_out/r03/c1_train_dev7.json 2> gpurun_out/r03/c1_train_dev7.err
+for wl in c1 c2; do
+timeout -k 10 120 python bench.py --workload $wl --steps 200 --warmup 20 > gpurun_out/r03/bench_${wl}_auto2.json 2> gpurun_out/r03/bench_${wl}_auto2.err
+timeout -k 10 120 python bench.py --workload $wl --steps 200 --warmup 20 --hipgraph > gpurun_out/r03/bench_${wl}_hipgraph2.json 2> gpurun_out/r03/bench_${wl}_hipgraph2.err
+done
+timeout -k 10 200 python bench.py --workload c3_130 --no-cpu-baseline > gpurun_out/r03/bench_c3_130b.json 2> gpurun_out/r03/bench_c3_130b.err
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03/prof_c1_train_dev7 -o c1train -- python3 $GRAFT_REPO_ROOT/bench.py --workload c1_train --dropout-mode device --no-secondary --no-cpu-baseline --steps 50 > $GRAFT_REPO_ROOT/gpurun_out/r03/prof_c1_train_dev7.log 2>&1
