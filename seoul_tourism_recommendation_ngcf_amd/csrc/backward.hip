@@ -305,41 +305,59 @@ __global__ __launch_bounds__(512) void bwd_weight_kernel(const float *__restrict
     if (tid < kBwM) partial_bias[(int64_t)blockIdx.x * kBwM + tid] = ((bs[tid] + bs[kBwM + tid]) + bs[2 * kBwM + tid]) + bs[3 * kBwM + tid];
 }
 
-__global__ void bwd_weight_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ partial_bias, int n_wg, int d_in,
-                                         int d_out, int P, float *__restrict__ gW1, int64_t ld1, float *__restrict__ gW2, int64_t ld2,
-                                         float *__restrict__ gb1, float *__restrict__ gb2)
+// 64 output elements per workgroup; its four waves each add a quarter of the partials (eight independent load chains, combined in
+// a fixed order), the quarters are added in wave order: the result does not depend on anything but n_wg.  (r03: one thread per
+// element walking all partials - and one per bias element walking them as a single dependent chain - took 26 us of load latency
+// on the Seoul graph's 93 partials.)
+__global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ partial_bias,
+                                                                int n_wg, int d_in, int d_out, float *__restrict__ gW1, int64_t ld1,
+                                                                float *__restrict__ gW2, int64_t ld2, float *__restrict__ gb1,
+                                                                float *__restrict__ gb2)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d_out * 2 * d_in) {
-        const int o = i - d_out * 2 * d_in;
-        if ((gb1 || gb2) && o < d_out) {
-            float s = 0.f;
-            for (int w = 0; w < n_wg; ++w) s += partial_bias[(int64_t)w * kBwM + o];
-            if (gb2) gb2[o] = s;
-            if (gb1) gb1[o] = 2.0f * s;          // b1 enters the layer twice (NGCF.py:131,133)
+    __shared__ float quarter[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n_w = d_out * 2 * d_in;
+    const int i = blockIdx.x * 64 + e;
+    const bool is_w = i < n_w, is_b = !is_w && (gb1 || gb2) && i - n_w < d_out;
+    float r = 0.f;
+    if (is_w || is_b) {
+        const float *p = is_w ? partial + i : partial_bias + (i - n_w);
+        const int64_t step = is_w ? (int64_t)n_w : (int64_t)kBwM;
+        const int per = (n_wg + 3) / 4, w0 = q * per, w1 = min(n_wg, w0 + per);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            s0 += p[(w + 0) * step];
+            s1 += p[(w + 1) * step];
+            s2 += p[(w + 2) * step];
+            s3 += p[(w + 3) * step];
+            s4 += p[(w + 4) * step];
+            s5 += p[(w + 5) * step];
+            s6 += p[(w + 6) * step];
+            s7 += p[(w + 7) * step];
         }
-        return;
+        if (w + 0 < w1) s0 += p[(w + 0) * step];
+        if (w + 1 < w1) s1 += p[(w + 1) * step];
+        if (w + 2 < w1) s2 += p[(w + 2) * step];
+        if (w + 3 < w1) s3 += p[(w + 3) * step];
+        if (w + 4 < w1) s4 += p[(w + 4) * step];
+        if (w + 5 < w1) s5 += p[(w + 5) * step];
+        if (w + 6 < w1) s6 += p[(w + 6) * step];
+        r = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     }
-    const int o = i / (2 * d_in), c = i % (2 * d_in);
-    // eight independent chains (workgroups w = q mod 8), combined in a fixed order: the loads of a chain do not wait for each other
-    const float *p = partial + i;
-    const int64_t step = (int64_t)d_out * 2 * d_in;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-    int w = 0;
-    for (; w + 8 <= n_wg; w += 8) {
-        s0 += p[(w + 0) * step];
-        s1 += p[(w + 1) * step];
-        s2 += p[(w + 2) * step];
-        s3 += p[(w + 3) * step];
-        s4 += p[(w + 4) * step];
-        s5 += p[(w + 5) * step];
-        s6 += p[(w + 6) * step];
-        s7 += p[(w + 7) * step];
+    quarter[q][e] = r;
+    __syncthreads();
+    if (q != 0) return;
+    r = ((quarter[0][e] + quarter[1][e]) + quarter[2][e]) + quarter[3][e];
+    if (is_w) {
+        const int o = i / (2 * d_in), c = i % (2 * d_in);
+        if (c < d_in) gW1[(int64_t)o * ld1 + c] = r;
+        else gW2[(int64_t)o * ld2 + (c - d_in)] = r;
+    } else if (is_b) {
+        const int o = i - n_w;
+        if (gb2) gb2[o] = r;
+        if (gb1) gb1[o] = 2.0f * r;          // b1 enters the layer twice (NGCF.py:131,133)
     }
-    for (; w < n_wg; ++w) s0 += p[w * step];
-    const float r = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-    if (c < d_in) gW1[(int64_t)o * ld1 + c] = r;
-    else gW2[(int64_t)o * ld2 + (c - d_in)] = r;
 }
 
 extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void)
@@ -375,7 +393,7 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
         bwd_weight_kernel<false><<<n_wg, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     LAUNCH_CHECK();
     const int total = d_out * 2 * d_in + ((gb1 || gb2) ? d_out : 0);
-    bwd_weight_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, partial_bias, n_wg, d_in, d_out, P, gW1, ld1, gW2, ld2, gb1, gb2);
+    bwd_weight_reduce_kernel<<<(total + 63) / 64, 256, 0, stream>>>(partial, partial_bias, n_wg, d_in, d_out, gW1, ld1, gW2, ld2, gb1, gb2);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -705,20 +723,22 @@ __global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const in
     for (int i = tid; i < P; i += kSortThreads)
         key[i] = i < M ? (K)(((K)idx[i] << 13) | (K)i) : (K)~(K)0;
     __syncthreads();
+    // one comparator per thread and pass: pair t exchanges i = (t with a zero bit inserted at log2 j) and i + j.  At j <= 64 the 64
+    // pairs of a wave stay inside one 128-key block, so those passes need no workgroup barrier - a wave's LDS operations complete in
+    // order - only the wait for its own outstanding ones (r03: 78 barriers for M = 3 072 before, 27 now).
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += kSortThreads) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const K a = key[i], b = key[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        key[i] = b;
-                        key[l] = a;
-                    }
+            for (int t = tid; t < (P >> 1); t += kSortThreads) {
+                const int i = 2 * t - (t & (j - 1)), l = i + j;
+                const K a = key[i], b = key[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[l] = a;
                 }
             }
-            __syncthreads();
+            if (j > 64 || j == 1) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
     // head flags + exclusive scan (chunks of kSortThreads, running carry)
     if (tid == 0) carry_s = 0;

@@ -1,5 +1,6 @@
 // dense.hip - the dense half of a layer on the fp32 matrix cores, and the fused layer entry point.
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // Dense half of a layer (NGCF.py:131-146) on the fp32 matrix cores.
@@ -540,6 +541,286 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
     }
 }
 
+#ifdef NGCF_LAB
+// ---------------------------------------------------------------------------------------------
+// LAB ONLY (-DNGCF_LAB; measured slower than layer_dense_resident_kernel: profiles/r03_dense_il_lab.txt).
+// The resident kernel with the finished tiles leaving UNDER the next tiles' K loop (r03).
+// layer_dense_resident_kernel ends a tile with 128 (256 with a carry) store instructions per wave in one burst and relies on the
+// second wave of the SIMD to keep the matrix pipe busy meanwhile.  Here a SIMD runs ONE wave with the whole register file (512
+// per lane: __launch_bounds__(256), one workgroup per CU) that owns TWO row tiles at a time (64 rows x 128 columns, 128 accumulator
+// registers; a B operand read from LDS feeds eight MFMAs).  The activated values of a finished pair stay in 128 registers (+ 32 row
+// scales) and the K loop of the wave's NEXT pair issues two stores after every group of eight MFMAs (16 groups per chunk, 8
+// chunks: 256 stores), so that a wave's memory traffic is spread evenly over its matrix work instead of alternating with it.  The
+// K loop is unrolled completely (NCH chunks, a template parameter: 8 for d_in 113..128, 9 for 129..144) - the element of the
+// previous pair a group stores is then a fixed register - and there is no branch in it: a store behind a branch makes the
+// compiler wait for every load in flight at the join.  Raw operands are requested one chunk (128 MFMAs = 3.4 us) ahead.  The first
+// pair of a wave runs the loop without stores, the last one leaves in a burst after the loop (with the bounds tests of a partial
+// tile).  Same k order and the same epilogue arithmetic as the other two kernels: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+constexpr int kIlWaves = 4;
+
+template <int NCH, bool CARRY, int LAB = 0>     // LAB (-DNGCF_LAB builds): 1 no stores, 2 no loads, +4 stores to L2-resident rows, +8 staged but not stored - wrong results, timing only
+__global__ __launch_bounds__(kIlWaves * 64) void layer_dense_resident_il_kernel(
+    const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ Es, int64_t ldE, int64_t n_rows, int d_in, int d_out,
+    const float *__restrict__ Wt, const float *__restrict__ bias2, float leaky, float drop_p, uint64_t drop_seed_in,
+    const float *__restrict__ drop_mask, int64_t ldm, float *__restrict__ carry, int64_t ldc, float *__restrict__ norm, int64_t ldn)
+{
+    const uint64_t drop_seed = drop_p > 0.f ? resolve_seed(drop_seed_in) : drop_seed_in;
+    constexpr int NT = 4, WCOLS = 128, TP = 1;   // TP: row tiles a wave works on at a time (2: 204 registers spilled)
+    extern __shared__ float Wres[];                 // [NCH * 32][128], the layout of pack_weights_kernel
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Wt);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Wres);
+        constexpr int n4 = NCH * NGCF_KC * WCOLS / 4;
+        for (int i = tid; i < n4; i += kIlWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t n_pairs = (n_rows + 32 * TP - 1) / (32 * TP);
+    const int d4 = (d_in + 3) & ~3;
+    const float *W = Wres + li * NT + lh * 4 * WCOLS;     // the lane's k rows of a group: 4 lh + sx
+    float bz[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bz[t] = bias2[t * 32 + li];
+    const int64_t pair_step = (int64_t)gridDim.x * kIlWaves;
+    const int ldn_i = (int)ldn, ldc_i = (int)ldc;          // (host: 64 rows of either fit 31 bits)
+    auto row_of = [&](int64_t pr, int u) {                 // the lane's row of tile u of pair pr (past the end: the last row, never stored)
+        int64_t g = pr * (32 * TP) + u * 32 + li;
+        return g < n_rows ? g : n_rows - 1;
+    };
+    // the lane's four 16-byte pieces of chunk C (le_l / e_l: the lane's row + 4 lh): only the LAST chunk can reach past the padded
+    // width (d_in > 16 (NCH - 1)), every other one is the row pointer + a constant
+    auto fetch = [&](auto Cc, const float *le_l, const float *e_l, f32x4 &la, f32x4 &lb, f32x4 &ea, f32x4 &eb) {
+        constexpr int C = decltype(Cc)::value;
+        if constexpr (LAB & 2) return;
+        if constexpr (C < NCH - 1) {
+            la = *reinterpret_cast<const f32x4 *>(le_l + C * NGCF_DC);
+            ea = *reinterpret_cast<const f32x4 *>(e_l + C * NGCF_DC);
+            lb = *reinterpret_cast<const f32x4 *>(le_l + C * NGCF_DC + 8);
+            eb = *reinterpret_cast<const f32x4 *>(e_l + C * NGCF_DC + 8);
+        } else {
+            const int ca = C * NGCF_DC + lh * 4, cb = ca + 8;
+            const int cca = (ca < d4 ? ca : d4 - 4) - lh * 4, ccb = (cb < d4 ? cb : d4 - 4) - lh * 4;
+            la = *reinterpret_cast<const f32x4 *>(le_l + cca);
+            ea = *reinterpret_cast<const f32x4 *>(e_l + cca);
+            lb = *reinterpret_cast<const f32x4 *>(le_l + ccb);
+            eb = *reinterpret_cast<const f32x4 *>(e_l + ccb);
+        }
+    };
+    f32x4 la[2][TP], lb[2][TP], ea[2][TP], eb[2][TP];   // the raw pieces of the next two chunks (set = chunk & 1)
+    if constexpr (LAB & 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < TP; ++u) la[q][u] = lb[q][u] = ea[q][u] = eb[q][u] = f32x4{0.01f * lane, 0.02f, 0.03f, 0.04f};
+    }
+    int64_t pair = (int64_t)blockIdx.x * kIlWaves + wave;
+    if (pair >= n_pairs) return;
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const int64_t g0 = row_of(pair, u);
+        fetch(std::integral_constant<int, 0>{}, LE + g0 * ldLE + lh * 4, Es + g0 * ldE + lh * 4, la[0][u], lb[0][u], ea[0][u], eb[0][u]);
+        fetch(std::integral_constant<int, 1>{}, LE + g0 * ldLE + lh * 4, Es + g0 * ldE + lh * 4, la[1][u], lb[1][u], ea[1][u], eb[1][u]);
+    }
+    f32x16 acc[TP][NT];
+    f32x16 pv[TP][NT];             // the previous pair: activated values, un-normalised (what `carry` receives)
+    float pinv[TP][16];            // and its row scales
+    float *pn = norm, *pc = carry; // the lane's 16 bytes (columns 4 li ..) of row 4 lh of the previous pair's destination
+    float *stg = Wres + NCH * NGCF_KC * WCOLS + wave * 512;   // the wave's two 1 KB slabs (a row pair each) for turning a row
+    f32x4 qn[TP][16], qc[TP][16];  // the previous tile as it leaves: lane = 16 bytes (columns 4 li ..) of row r (+ 4 lh), normalised / carry
+    f32x4 lab_sink = {0.f, 0.f, 0.f, 0.f};
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const bool any_drop = drop_mask || drop_p > 0.f;
+
+    // one chunk: sums / products from the raw pieces, the next chunk requested (NXT: of the next pair), 16 groups of (B operand of
+    // the next group from LDS, eight MFMAs, two stores of the previous pair)
+    auto chunk = [&](auto Cc, auto STc, const float *const (&le_row)[TP], const float *const (&e_row)[TP],
+                     const float *const (&le_nxt)[TP], const float *const (&e_nxt)[TP]) {
+        constexpr int C = decltype(Cc)::value;
+        constexpr bool ST = decltype(STc)::value;
+        f32x4 a4[TP][4];
+        constexpr int S = C & 1;
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            if constexpr (C == NCH - 1) {
+                const int ca = C * NGCF_DC + lh * 4, cb = ca + 8;
+                if (cb + 4 > d_in) {                      // only the last chunk of an odd width
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (ca + q >= d_in) la[S][u][q] = 0.f, ea[S][u][q] = 0.f;
+                        if (cb + q >= d_in) lb[S][u][q] = 0.f, eb[S][u][q] = 0.f;
+                    }
+                }
+            }
+            a4[u][0] = la[S][u] + ea[S][u], a4[u][1] = lb[S][u] + eb[S][u], a4[u][2] = la[S][u] * ea[S][u], a4[u][3] = lb[S][u] * eb[S][u];
+            // the chunk after next - of this tile, or chunk 0 / 1 of the wave's next one (NCH odd: the sets swap roles from tile to
+            // tile, which a fixed register assignment cannot follow; then chunk NCH - 1 leaves its set to chunk 1 of the next tile
+            // and chunk 0 is requested by chunk NCH - 2 into the other one ... only for even NCH; odd NCH: see k_loop)
+            if constexpr (C + 2 < NCH) fetch(std::integral_constant<int, C + 2>{}, le_row[u], e_row[u], la[S][u], lb[S][u], ea[S][u], eb[S][u]);
+            else if constexpr ((NCH & 1) == 0)
+                fetch(std::integral_constant<int, C + 2 - NCH>{}, le_nxt[u], e_nxt[u], la[S][u], lb[S][u], ea[S][u], eb[S][u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float *wc = W + C * NGCF_KC * WCOLS;
+        f32x4 bv = *reinterpret_cast<const f32x4 *>(wc);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int kb = g >> 2, sx = g & 3;
+            f32x4 bn = bv;
+            if (g < 15) bn = *reinterpret_cast<const f32x4 *>(wc + (((g + 1) >> 2) * 8 + ((g + 1) & 3)) * WCOLS);
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.x, acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.y, acc[u][1], 0, 0, 0);
+                acc[u][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.z, acc[u][2], 0, 0, 0);
+                acc[u][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.w, acc[u][3], 0, 0, 0);
+                if constexpr (ST && C < 8 && !(LAB & 1)) {
+                    // chunk C stores rows r = 2 C and 2 C + 1 (of both halves lh) of the previous tile: four 16-byte stores, four
+                    // groups apart (the values were turned and scaled by activate(): instructions between the MFMAs of this loop
+                    // cost several times what they cost there - tools/dense_il_parts_lab.py)
+                    if ((g & 3) == 2) {
+                        const int js = g >> 3, rs = 2 * C + js, ros = u * 32 + (rs & 3) + 8 * (rs >> 2);
+                        if constexpr (LAB & 8) lab_sink += qn[u][rs];
+                        else if ((g >> 2 & 1) == 0) *reinterpret_cast<f32x4 *>(pn + ros * ldn_i) = qn[u][rs];
+                        else if (CARRY) *reinterpret_cast<f32x4 *>(pc + ros * ldc_i) = qc[u][rs];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bv = bn;
+        }
+    };
+    auto k_loop = [&](auto STc, int64_t pr) {
+        const float *le_row[TP], *e_row[TP], *le_nxt[TP], *e_nxt[TP];
+        const int64_t nx = pr + pair_step < n_pairs ? pr + pair_step : pr;   // (the last pair of a wave re-reads its own first chunk)
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            const int64_t g = row_of(pr, u), gn = row_of(nx, u);
+            le_row[u] = LE + g * ldLE + lh * 4, e_row[u] = Es + g * ldE + lh * 4;
+            le_nxt[u] = LE + gn * ldLE + lh * 4, e_nxt[u] = Es + gn * ldE + lh * 4;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][tt][r] = 0.f;
+        }
+        chunk(std::integral_constant<int, 0>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 1>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 2>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 3>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 4>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 5>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 6>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        chunk(std::integral_constant<int, 7>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        if constexpr (NCH > 8) chunk(std::integral_constant<int, 8>{}, STc, le_row, e_row, le_nxt, e_nxt);
+        if constexpr (NCH & 1) {     // odd: both sets are free only now
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                fetch(std::integral_constant<int, 0>{}, le_nxt[u], e_nxt[u], la[0][u], lb[0][u], ea[0][u], eb[0][u]);
+                fetch(std::integral_constant<int, 1>{}, le_nxt[u], e_nxt[u], la[1][u], lb[1][u], ea[1][u], eb[1][u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // bias, LeakyReLU, dropout, row scale: acc -> pv, pinv, pn, pc
+    auto activate = [&](int64_t pr) {
+        const int64_t row0 = pr * (32 * TP);
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            float rowss[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
+            if (!any_drop) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[u][tt][r] + bz[tt];
+                        v = v >= 0.f ? v : leaky * v;
+                        pv[u][tt][r] = v;
+                        rowss[r] = fmaf(v, v, rowss[r]);
+                    }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int col = tt * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[u][tt][r] + bz[tt];
+                        v = v >= 0.f ? v : leaky * v;
+                        const int64_t grow = row0 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (drop_mask) v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
+                        else {
+                            const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                            v = h < drop_thr ? 0.f : v * keep_scale;
+                        }
+                        pv[u][tt][r] = v;
+                        rowss[r] = fmaf(v, v, rowss[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s2 = rowss[r];
+                s2 += __shfl_xor(s2, 1);
+                s2 += __shfl_xor(s2, 2);
+                s2 += __shfl_xor(s2, 4);
+                s2 += __shfl_xor(s2, 8);
+                s2 += __shfl_xor(s2, 16);
+                pinv[u][r] = 1.f / fmaxf(sqrtf(s2), 1e-12f);   // F.normalize eps, NGCF.py:144
+            }
+            // a lane holds 4 values of a row 32 columns apart; through a wave-private 1 KB slab of LDS (two, alternating) they
+            // become 16 contiguous bytes per lane: a store instruction then writes two complete rows
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) stg[(r & 1) * 256 + lh * 128 + tt * 32 + li] = pv[u][tt][r];
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(stg + (r & 1) * 256 + lane * 4);
+                qn[u][r] = q * pinv[u][r];
+                if (CARRY) qc[u][r] = q;
+            }
+        }
+        const int64_t dst0 = (LAB & 4) ? ((int64_t)blockIdx.x * kIlWaves + wave) * (32 * TP) : row0;   // lab: every tile to the wave's first rows (L2 hits)
+        pn = norm + (dst0 + 4 * lh) * ldn + 4 * li;
+        if (CARRY) pc = carry + (dst0 + 4 * lh) * ldc + 4 * li;
+    };
+
+    k_loop(std::false_type{}, pair);
+    activate(pair);
+    int64_t prev = pair;
+    for (pair += pair_step; pair < n_pairs; pair += pair_step) {
+        k_loop(std::true_type{}, pair);               // stores pair `prev` (full: it is not the last one) on the way
+        activate(pair);
+        prev = pair;
+    }
+    // the wave's last pair leaves in a burst
+    if constexpr (LAB & 1) {           // (one store keeps the arithmetic alive)
+        f32x4 x = lab_sink;
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x += qn[u][r] + (CARRY ? qc[u][r] : qn[u][r]);
+        if (x.x + x.y + x.z + x.w == 1.2345f) norm[0] = x.x;
+        return;
+    }
+    const int64_t row0 = prev * (32 * TP);
+#pragma unroll
+    for (int u = 0; u < TP; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = u * 32 + (r & 3) + 8 * (r >> 2);
+            if (row0 + ro + 4 * lh >= n_rows) continue;
+            *reinterpret_cast<f32x4 *>(pn + ro * ldn_i) = qn[u][r];
+            if (CARRY) *reinterpret_cast<f32x4 *>(pc + ro * ldc_i) = qc[u][r];
+        }
+    if constexpr (LAB & 8)
+        if (lab_sink.x + lab_sink.y + lab_sink.z + lab_sink.w == 1.2345f) norm[1] = lab_sink.x;
+}
+
+#endif  // NGCF_LAB
+
 // ---------------------------------------------------------------------------------------------
 // 256 / 512 output columns with NO operand in LDS (r02).  At these widths a workgroup of layer_dense_kernel owns 32 (or 64) rows
 // and each of its waves its own 128 output columns: the weights a wave multiplies by are shared with nobody, yet a 32 / 64 KB
@@ -807,6 +1088,54 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_set[dev_i] = true;
             }
+#ifdef NGCF_LAB
+            // resident == 2: the finished tile leaves under the next tile's K loop (layer_dense_resident_il_kernel; full 128
+            // output columns, 8 or 9 chunks)
+            if (resident == 2 && d_out == 128 && (n_chunks == 8 || n_chunks == 9) && ldn < (1 << 24) && ldc < (1 << 24) && ldn % 4 == 0 &&
+                aligned16(norm) && (!carry || (ldc % 4 == 0 && aligned16(carry)))) {
+                const int64_t il_lds = lds_bytes + kIlWaves * 2048;      // + two 1 KB slabs per wave
+#define NGCF_IL(NCH, CARRY) \
+    do { \
+        static bool il_set[kMaxDevices] = {}; \
+        if (!il_set[dev_i]) { \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_il_kernel<NCH, CARRY>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            il_set[dev_i] = true; \
+        } \
+        layer_dense_resident_il_kernel<NCH, CARRY><<<dim3(kResWGs), kIlWaves * 64, (size_t)il_lds, stream>>>( \
+            LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc, norm, ldn); \
+    } while (0)
+#define NGCF_IL_LAB(L) \
+    layer_dense_resident_il_kernel<8, true, L><<<dim3(kResWGs), kIlWaves * 64, (size_t)il_lds, stream>>>( \
+        LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc, norm, ldn)
+                if (const int lab = ngcf_opts().dense_il_lab; lab && n_chunks == 8 && carry) {
+                    static bool lab_set = false;
+                    if (!lab_set) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_il_kernel<8, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_il_kernel<8, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_il_kernel<8, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_il_kernel<8, true, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident_il_kernel<8, true, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        lab_set = true;
+                    }
+                    switch (lab) {
+                    case 1: NGCF_IL_LAB(1); break;
+                    case 2: NGCF_IL_LAB(2); break;
+                    case 3: NGCF_IL_LAB(3); break;
+                    case 6: NGCF_IL_LAB(6); break;       // no loads, every store to the wave's first tile
+                    default: NGCF_IL_LAB(10); break;     // no loads, the stored values formed (LDS round trip, scaling) but not stored
+                    }
+                    LAUNCH_CHECK();
+                    return NGCF_OK;
+                }
+#undef NGCF_IL_LAB
+                if (n_chunks == 8) { if (carry) NGCF_IL(8, true); else NGCF_IL(8, false); }
+                else { if (carry) NGCF_IL(9, true); else NGCF_IL(9, false); }
+#undef NGCF_IL
+                LAUNCH_CHECK();
+                return NGCF_OK;
+            }
+#endif
             layer_dense_resident_kernel<<<dim3(kResWGs), kResWaves * 64, (size_t)lds_bytes, stream>>>(
                 LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc,
                 norm, ldn);

@@ -855,11 +855,14 @@ def test_odd_shapes_against_oracle(U, I, inter, d0, layers, B, dev):
     assert abs(float(loss) - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-6
 
 
-@pytest.mark.parametrize("d_in,d_out,mode", [(128, 128, "eval"), (130, 128, "hash"), (64, 100, "mask"), (144, 128, "last")])
+@pytest.mark.parametrize("d_in,d_out,mode", [(128, 128, "eval"), (130, 128, "hash"), (64, 100, "mask"), (144, 128, "last"),
+                                             (120, 128, "mask"), (128, 128, "last"), (113, 128, "hash")])
 def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, mode, dev, lib_options):
     """layer_dense_resident_kernel (weights resident in LDS, no barriers; taken from 131 072 rows on at 97..128 output columns)
-    against layer_dense_kernel on the same inputs: the k order of every output element is the same, so carry and normalised
-    block must agree bit for bit - in eval mode, with the hash dropout, with a host-drawn noise tensor, and without a carry."""
+    and - in a library built with -DNGCF_LAB, otherwise 2 means 1 - layer_dense_resident_il_kernel (dense_resident = 2: one wave per
+    SIMD, the finished tile stored under the next tile's K loop; 128 output columns, 8 or 9 chunks) against layer_dense_kernel on the same inputs: the k order of every output element
+    is the same, so carry and normalised block must agree bit for bit - in eval mode, with the hash dropout, with a host-drawn
+    noise tensor, and without a carry."""
     import os
     eng = _pkg().engine
     n = 140_001                                              # above the kernel's threshold; not a multiple of 32: a partial last tile
@@ -872,15 +875,16 @@ def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, m
     mask = (torch.rand((n, d_out), generator=g) > 0.3).float().to(dev) / 0.7 if mode == "mask" else None
     kw = dict(drop_p=0.3 if mode in ("hash", "mask") else 0.0, drop_seed=77 if mode == "hash" else 0, drop_mask=mask)
     outs = []
-    for resident in (1, 0):
+    for resident in (1, 0, 2):
         lib_options(dense_resident=resident)
-        carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
+        carry = None if mode == "last" else torch.full((n, d_out), 5.0, device=dev)
         norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]                # a column slice of a wider matrix
         eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
         outs.append((carry, norm.clone()))
-    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][1], outs[1][1])
+    assert bool((norm.as_strided((n, 3), (d_out + 3, 1), d_out) == 7.0).all())      # nothing written past the slice
     if mode != "last":
-        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[1][0])
         if mode == "hash":
             frac = float((outs[0][0] == 0).float().mean())
             assert abs(frac - 0.3) < 0.01
