@@ -465,6 +465,83 @@ def main():
 
     torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
     dt, loss, n_launch, spmm_ms = timed(step, True)
+    n_layer = len(layers)
+
+    def build_line(dt, loss, n_launch, spmm_ms, sh, spmm_shapes, local_nnz):
+        """The JSON line of a finished headline measurement (secondaries are attached by the caller)."""
+        edges_per_step = n_layer * nnz                            # whole job, all ranks
+        value = edges_per_step * args.steps / dt
+        # roofline of the dominant kernel (spmm_kernel), this rank: algorithmic bytes per launch / mean duration
+        per_launch = sum(spmm_model_a_bytes(z, r_, c_, d0) for z, r_, c_ in spmm_shapes) / len(spmm_shapes)
+        mean_ms = spmm_ms.value / max(n_launch.value, 1)
+        achieved = per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")    # PMC-measured HBM bytes per launch (rocprofv3 --pmc)
+        if os.path.exists(tpath) and world == 1:
+            rec = json.load(open(tpath)).get(args.workload + ("_uniform" if args.uniform_items else ""))
+            if rec and rec.get("seg_len", 0) == (args.seg_len or rec.get("seg_len", 0)):
+                traffic = rec["hbm_bytes_per_spmm_launch"]
+                traffic_source = ("profiles/traffic.json - NOT measured in this run: separate rocprofv3 --pmc passes of this "
+                                  "command (tools/pmc.sh), " + rec.get("version", "") + ", " + rec.get("collected", ""))
+        gather_bytes = (local_nnz / max(len(spmm_shapes), 1) if world > 1 else nnz) * d0 * 4
+
+        swept = [csr.swept_rows] if world == 1 else sh.swept_rows()
+        kernel_name = ("spmm_swept_kernel (one L.E product: a launch per row group + fix-up)" if all(swept) else
+                       "spmm_kernel + spmm_sliced_kernel (one L.E product)" if not any(swept) else
+                       "spmm_swept_kernel / spmm_kernel (one L.E product, mean over the rank's two products)")
+        out = {
+            "metric": "NGCF 3-layer forward: propagated edges/sec + achieved HBM GB/s, d=128",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {'Seoul-shaped stand-in' if seoul else 'synthetic bipartite'} {n_user} users x {n_item} items, "
+                                   f"{coo['interactions']} interactions, nnz(L)={nnz}, d0={d0}, layers={list(layers)}, "
+                                   f"batch={args.batch}, seed={seed}" + (", uniform items" if args.uniform_items else ""),
+                       "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
+                       "d": d0, "n_layers": n_layer, "batch": args.batch,
+                       "hipgraph": bool(args.hipgraph),
+                       "parallelism": "single GPU" if world == 1 else
+                       f"row-partition x{world}, exchange={args.exchange} ({ngcf_dist.SCHEME_NOTES[args.exchange]}), transport={sh.backend}"
+                       + (f" (p2p fell back: {sh.p2p_error})" if getattr(sh, "p2p_error", None) else "")},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
+                         "traffic_source": traffic_source,
+                         "mean_launch_ms": mean_ms, "swept_rows": swept},
+            # what actually bounds the SpMM on a graph without locality: every stored entry gathers one row slice of E through
+            # the vector L1 from L2 (4*d bytes per entry, 26x the algorithmic bytes at C3); see DESIGN.md 4.1
+            "roofline_l2": {"bound": "l2-gather", "kernel": kernel_name, "achieved": gather_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0,
+                            "peak": L2_PEAK_GBS, "unit": "GB/s",
+                            "frac": (gather_bytes / (mean_ms * 1e-3) / 1e9 / L2_PEAK_GBS) if mean_ms > 0 else 0.0,
+                            "gather_bytes_per_launch": gather_bytes,
+                            "note": "explanatory, not the headline: roofline.frac stays SURVEY 8d model A"},
+            "loss": float(loss),
+        }
+        return out
+
+    # N > 1: what follows the headline (the RCCL cross-check, the other exchange scheme) must not be able to lose it: a
+    # collective that never completes would otherwise hold every rank until the process group's timeout aborts the job.  A
+    # watchdog prints the finished headline and ends the process if the secondaries overrun their budget.
+    watchdog = None
+    if world > 1 and not args.no_secondary:
+        import threading
+        budget = float(os.environ.get("NGCF_BENCH_SECONDARY_TIMEOUT_S", "240"))
+        fallback = build_line(dt, loss, n_launch, spmm_ms, sh, spmm_shapes, local_nnz)
+        fallback["secondary"] = {"error": f"the secondary measurements did not finish within {budget:.0f} s; this line was printed by the watchdog"}
+        fallback["cpu_baseline"] = None
+        line_lock, line_done = threading.Lock(), [False]
+
+        def overrun():
+            with line_lock:
+                if line_done[0]:
+                    return
+                line_done[0] = True
+                if rank == 0:
+                    print(json.dumps(fallback), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(budget + (0.0 if rank == 0 else 5.0), overrun)
+        watchdog.daemon = True
+        watchdog.start()
     transport_check = None
     if world > 1 and sh.backend == "p2p" and not args.no_secondary:
         # The same scheme over torch.distributed collectives (RCCL), timed the same way: a cross-check of the p2p transport's
@@ -489,23 +566,6 @@ def main():
         except Exception as exc:  # noqa: BLE001
             os.environ.pop("NGCF_DIST_COLLECTIVES", None)
             transport_check = {"p2p": {"ms_per_step": dt / args.steps * 1e3, "loss": float(loss)}, "torch_rccl": {"error": repr(exc)[:300]}}
-
-    n_layer = len(layers)
-    edges_per_step = n_layer * nnz                            # whole job, all ranks
-    value = edges_per_step * args.steps / dt
-    # roofline of the dominant kernel (spmm_kernel), this rank: algorithmic bytes per launch / mean duration
-    per_launch = sum(spmm_model_a_bytes(z, r_, c_, d0) for z, r_, c_ in spmm_shapes) / len(spmm_shapes)
-    mean_ms = spmm_ms.value / max(n_launch.value, 1)
-    achieved = per_launch / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")    # PMC-measured HBM bytes per launch (rocprofv3 --pmc)
-    if os.path.exists(tpath) and world == 1:
-        rec = json.load(open(tpath)).get(args.workload + ("_uniform" if args.uniform_items else ""))
-        if rec and rec.get("seg_len", 0) == (args.seg_len or rec.get("seg_len", 0)):
-            traffic = rec["hbm_bytes_per_spmm_launch"]
-            traffic_source = ("profiles/traffic.json - NOT measured in this run: separate rocprofv3 --pmc passes of this "
-                              "command (tools/pmc.sh), " + rec.get("version", "") + ", " + rec.get("collected", ""))
-    gather_bytes = (local_nnz / max(len(spmm_shapes), 1) if world > 1 else nnz) * d0 * 4
 
     secondary = {}
     if world > 1 and not args.no_secondary:
@@ -597,38 +657,7 @@ def main():
             secondary["c1_train_device_masks_hipgraph"] = {"error": repr(exc)[:300]}
         torch.set_grad_enabled(False)
 
-    swept = [csr.swept_rows] if world == 1 else sh.swept_rows()
-    kernel_name = ("spmm_swept_kernel (one L.E product: a launch per row group + fix-up)" if all(swept) else
-                   "spmm_kernel + spmm_sliced_kernel (one L.E product)" if not any(swept) else
-                   "spmm_swept_kernel / spmm_kernel (one L.E product, mean over the rank's two products)")
-    out = {
-        "metric": "NGCF 3-layer forward: propagated edges/sec + achieved HBM GB/s, d=128",
-        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {'Seoul-shaped stand-in' if seoul else 'synthetic bipartite'} {n_user} users x {n_item} items, "
-                               f"{coo['interactions']} interactions, nnz(L)={nnz}, d0={d0}, layers={list(layers)}, "
-                               f"batch={args.batch}, seed={seed}" + (", uniform items" if args.uniform_items else ""),
-                   "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": nnz,
-                   "d": d0, "n_layers": n_layer, "batch": args.batch,
-                   "hipgraph": bool(args.hipgraph),
-                   "parallelism": "single GPU" if world == 1 else
-                   f"row-partition x{world}, exchange={args.exchange} ({ngcf_dist.SCHEME_NOTES[args.exchange]}), transport={sh.backend}"
-                   + (f" (p2p fell back: {sh.p2p_error})" if getattr(sh, "p2p_error", None) else "")},
-        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
-                     "traffic_source": traffic_source,
-                     "mean_launch_ms": mean_ms, "swept_rows": swept},
-        # what actually bounds the SpMM on a graph without locality: every stored entry gathers one row slice of E through
-        # the vector L1 from L2 (4*d bytes per entry, 26x the algorithmic bytes at C3); see DESIGN.md 4.1
-        "roofline_l2": {"bound": "l2-gather", "kernel": kernel_name, "achieved": gather_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0,
-                        "peak": L2_PEAK_GBS, "unit": "GB/s",
-                        "frac": (gather_bytes / (mean_ms * 1e-3) / 1e9 / L2_PEAK_GBS) if mean_ms > 0 else 0.0,
-                        "gather_bytes_per_launch": gather_bytes,
-                        "note": "explanatory, not the headline: roofline.frac stays SURVEY 8d model A"},
-        "loss": float(loss),
-    }
+    out = build_line(dt, loss, n_launch, spmm_ms, sh if world > 1 else None, spmm_shapes, local_nnz)
     if transport_check:
         out["transport_check"] = transport_check
     if secondary:
@@ -644,6 +673,12 @@ def main():
     if rank == 0 and out["cpu_baseline"]:
         out["parity"] = out["cpu_baseline"].pop("parity")     # the oracle as the checker, beside it as the baseline
         assert out["parity"]["ok"], f"engine disagrees with the CPU oracle: {out['parity']}"
+    if watchdog is not None:
+        with line_lock:
+            if line_done[0]:                                  # the watchdog is printing / has printed
+                time.sleep(3600)
+            line_done[0] = True
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -389,22 +389,38 @@ class P2PExchange:
         tok = [os.urandom(8).hex() if self.rank == 0 else None]
         dist.broadcast_object_list(tok, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self.name = f"ngcf_p2p_{tok[0]}"
-        h = C.c_void_p()
-        with _eng._on(self.dev):
-            _lib.check(lib.ngcf_p2p_create(self.rank, self.world, max(self.n_floats, 64) * 4, self.name.encode(), C.byref(h)))
-        self._h = h
+        # Every rank takes part in every collective of this constructor whatever happened to it locally (a rank that raised
+        # between two of them would leave the others waiting in the next one): failures travel with the gathered objects and
+        # all ranks raise together.
+        h, err = C.c_void_p(), None
         mine = (C.c_char * 64)()
-        _lib.check(lib.ngcf_p2p_handle(self._h, mine))
-        handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(mine.raw), group=group)
-        blob = (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(handles))
-        with _eng._on(self.dev):
-            _lib.check(lib.ngcf_p2p_connect(self._h, blob))
+        try:
+            with _eng._on(self.dev):
+                _lib.check(lib.ngcf_p2p_create(self.rank, self.world, max(self.n_floats, 64) * 4, self.name.encode(), C.byref(h)))
+            _lib.check(lib.ngcf_p2p_handle(h, mine))
+        except Exception as exc:  # noqa: BLE001
+            err = f"rank {self.rank}: {exc!r}"[:300]
+        self._h = h
+        got = [None] * self.world
+        dist.all_gather_object(got, (err, bytes(mine.raw)), group=group)
+        errs = [e for e, _ in got if e]
+        if not errs:
+            try:
+                blob = (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(hb for _, hb in got))
+                with _eng._on(self.dev):
+                    _lib.check(lib.ngcf_p2p_connect(self._h, blob))
+            except Exception as exc:  # noqa: BLE001
+                err = f"rank {self.rank}: {exc!r}"[:300]
+            got2 = [None] * self.world
+            dist.all_gather_object(got2, err, group=group)      # (doubles as the barrier: everyone is connected before the first pull)
+            errs = [e for e in got2 if e]
+        if errs:
+            self.close_quietly()
+            raise RuntimeError("p2p exchange could not be set up: " + "; ".join(errs))
         self.base = int(lib.ngcf_p2p_local(self._h))
         self._mem = torch.as_tensor(_DevMem(self.base, max(self.n_floats, 64)), device=self.dev)
         assert self._mem.data_ptr() == self.base and self._mem.dtype == torch.float32
         self.seq = {}                      # slot -> last published / expected step
-        dist.barrier(group=group)          # everyone is connected before the first pull
 
     def floats(self, offset: int, n: int) -> torch.Tensor:
         assert 0 <= offset and offset + n <= self.n_floats
@@ -457,6 +473,14 @@ class P2PExchange:
         t = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(t.item()))
+
+    def close_quietly(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _lib.load().ngcf_p2p_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:  # noqa: BLE001
+            pass
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -28,3 +28,6 @@ pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:9000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+print(s.getvalue()[:9000])
