@@ -992,6 +992,254 @@ __global__ __launch_bounds__(CW * 64) void layer_dense_direct_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 / 512 output columns on a FEW THOUSAND rows, balanced over the whole chip (r03; VERDICT r2 #7: the Seoul shape).
+// layer_dense_direct_kernel gives a workgroup 32 complete rows: 5 940 rows are 186 workgroups on 256 CUs and every wave multiplies
+// 32 rows x 128 columns x K - 2 060 MFMAs at 515 -> 512, 55 us before anything else.  What balances is three 32 x 32 tiles per
+// SIMD: 186 x 16 tiles / 1 024 SIMDs = 2.9.  Here a workgroup owns 96 rows x 128 columns and each of its four waves THREE row
+// tiles of ONE 32-column tile (62 x 4 = 248 workgroups, 1 545 MFMAs per wave = 41 us): the rows of LE / E go through LDS once per
+// workgroup (sums and products formed on the way in, double-buffered, one barrier per chunk) and feed all four waves; a wave's
+// weights come straight from the packed matrix (a lane's four k-values of a k-block are 16 contiguous bytes: pack_weights_tall_kernel),
+// one chunk ahead.  A row is no longer complete inside a workgroup, so the kernel writes the activated values into BOTH outputs
+// and row_scale_kernel turns the `norm` rows into unit rows in place - adding the squares in exactly the order the other dense
+// kernels use (per 128-column panel: four columns 32 apart per lane, butterfly over 32 lanes; panels in order), so the results
+// are bit-identical to theirs.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTallRows = 96;
+
+// Wp[chunk][ct][kb][lh][li][sx] = packed k-row kb*8 + lh*4 + sx (0..15: W1 column chunk*16 + kl, 16..31: W2 column chunk*16 + kl - 16)
+// of output column ct*32 + li; zero outside the matrices
+__global__ __launch_bounds__(256) void pack_weights_tall_kernel(const float *__restrict__ W1, const float *__restrict__ b1,
+                                                                const float *__restrict__ W2, const float *__restrict__ b2, int d_in,
+                                                                int d_out, int DOP, float *__restrict__ Wp, float *__restrict__ bias2)
+{
+    __shared__ float tile[NGCF_KC][33];
+    const int n_ct = DOP / 32;
+    const int chunk = blockIdx.x / n_ct, ct = blockIdx.x % n_ct;
+    for (int idx = threadIdx.x; idx < 32 * NGCF_KC; idx += 256) {
+        const int j = idx / NGCF_KC, kl = idx % NGCF_KC;          // consecutive threads: consecutive input columns of one output row
+        const int oc = ct * 32 + j, col = chunk * NGCF_DC + (kl % NGCF_DC);
+        float v = 0.f;
+        if (oc < d_out && col < d_in) v = (kl < NGCF_DC ? W1 : W2)[(int64_t)oc * d_in + col];
+        tile[kl][j] = v;
+    }
+    __syncthreads();
+    float *dst = Wp + ((int64_t)chunk * n_ct + ct) * (32 * NGCF_KC);
+    for (int idx = threadIdx.x; idx < 32 * NGCF_KC; idx += 256) {
+        const int sx = idx & 3, li = (idx >> 2) & 31, lh = (idx >> 7) & 1, kb = idx >> 8;
+        dst[idx] = tile[kb * 8 + lh * 4 + sx][li];
+    }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < DOP; j += 256)
+            bias2[j] = j < d_out ? (b1[j] + b1[j]) + b2[j] : 0.f;   // b1 is added twice, NGCF.py:131,133
+}
+
+template <int LAB>      // LAB (-DNGCF_LAB builds, timing only): 1 no barriers, 2 no row staging, 4 no weight loads in the loop
+__global__ __launch_bounds__(256) void layer_dense_tall_kernel(
+    const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ Es, int64_t ldE, int64_t n_rows, int d_in, int d_out,
+    const float *__restrict__ Wp, const float *__restrict__ bias2, int n_chunks, int n_ct, float leaky, float drop_p,
+    uint64_t drop_seed_in, const float *__restrict__ drop_mask, int64_t ldm, float *__restrict__ carry, int64_t ldc,
+    float *__restrict__ norm, int64_t ldn)
+{
+    const uint64_t drop_seed = drop_p > 0.f ? resolve_seed(drop_seed_in) : drop_seed_in;
+    constexpr int XLD = NGCF_KC + 4;               // 36: [16 sums | 16 products | pad], b128 reads of a column block conflict-free
+    constexpr int MT = kTallRows / 32;             // row tiles per wave
+    constexpr int XBUF = kTallRows * XLD;          // floats of one LDS buffer
+    __shared__ float Xs[3 * XBUF];                 // THREE buffers: see the step comment below
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_cp = n_ct / 4;
+    const int64_t row0 = (int64_t)(blockIdx.x / n_cp) * kTallRows;
+    const int ct = (blockIdx.x % n_cp) * 4 + wave;                    // the wave's 32-column tile
+    const int d4 = (d_in + 3) & ~3;
+    // staging: 96 rows x 4 pieces of 16 bytes per operand and chunk = 384 pieces: thread t takes pieces t and t + 256 (< 384)
+    const bool two = tid < 384 - 256;
+    int64_t grow_a = row0 + (tid >> 2), grow_b = row0 + 64 + (tid >> 2);
+    grow_a = grow_a < n_rows ? grow_a : n_rows - 1;                   // rows past the end re-read the last row, never stored
+    grow_b = two ? (grow_b < n_rows ? grow_b : n_rows - 1) : grow_a;
+    const int sq4 = (tid & 3) * 4;
+    const float *le_a = LE + grow_a * ldLE + sq4, *e_a = Es + grow_a * ldE + sq4, *le_b = LE + grow_b * ldLE + sq4, *e_b = Es + grow_b * ldE + sq4;
+    const int last = n_chunks - 1;
+    const int cc_last = (last * NGCF_DC + sq4 < d4 ? last * NGCF_DC + sq4 : d4 - 4) - sq4;   // the last chunk may reach past the padded width
+    struct XRegs { f32x4 al, ae, bl, be; };     // a thread's pieces of one chunk: rows tid / 4 and 64 + tid / 4
+    XRegs x0, x1;                               // TWO chunks in flight: the rows come from beyond the L2 (12 MB each on the Seoul graph),
+                                                // one chunk of MFMAs (1.3 us) does not cover that latency
+    auto load_x = [&](int c, XRegs &x) {        // c <= last (callers clamp); every load unconditional (a load behind a branch cannot be counted)
+        const int off = c < last ? c * NGCF_DC : cc_last;
+        x.al = *reinterpret_cast<const f32x4 *>(le_a + off);
+        x.ae = *reinterpret_cast<const f32x4 *>(e_a + off);
+        x.bl = *reinterpret_cast<const f32x4 *>(le_b + off);
+        x.be = *reinterpret_cast<const f32x4 *>(e_b + off);
+    };
+    float *xs_w = Xs + (tid >> 2) * XLD + sq4;
+    auto store_x = [&](int c, int buf, XRegs x) {
+        if (c == last) {                        // only the last chunk can hold columns past d_in: they contribute zeros
+            const int c0 = c * NGCF_DC + sq4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0 + q >= d_in) x.al[q] = 0.f, x.ae[q] = 0.f, x.bl[q] = 0.f, x.be[q] = 0.f;
+        }
+        float *xr = xs_w + buf * XBUF;
+        *reinterpret_cast<f32x4 *>(xr) = x.al + x.ae;
+        *reinterpret_cast<f32x4 *>(xr + NGCF_DC) = x.al * x.ae;
+        if (two) {
+            *reinterpret_cast<f32x4 *>(xr + 64 * XLD) = x.bl + x.be;
+            *reinterpret_cast<f32x4 *>(xr + 64 * XLD + NGCF_DC) = x.bl * x.be;
+        }
+    };
+    const float *wl = Wp + (int64_t)ct * (32 * NGCF_KC) + lane * 4;    // chunk c, k-block kb: + c * n_ct * 1024 + kb * 256
+    const int64_t wstep = (int64_t)n_ct * (32 * NGCF_KC);
+    f32x4 b0[4], b1[4];
+    auto load_b = [&](int c, f32x4 (&b)[4]) {
+        const float *w = wl + (int64_t)c * wstep;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) b[kb] = *reinterpret_cast<const f32x4 *>(w + kb * 256);
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const float *xs_r = Xs + li * XLD + lh * 4;
+    auto read_a = [&](int buf, int kb, f32x4 (&a)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            a[m] = *reinterpret_cast<const f32x4 *>(xs_r + buf * XBUF + m * 32 * XLD + (kb >> 1) * NGCF_DC + (kb & 1) * 8);
+    };
+    // One wave per SIMD: nobody else covers a latency, so every operand is requested a step ahead.
+    // At the top of step c: LDS buffers c % 3 and (c + 1) % 3 hold chunks c and c + 1; `an` holds the first k-block of chunk c
+    // (read from LDS at the end of step c - 1); register set c & 1 holds the rows of chunk c + 2 and set (c + 1) & 1 those of
+    // chunk c + 3 (in flight).  Step c: the MFMAs of chunk c (k-block kb + 1 read from LDS before the MFMAs of k-block kb);
+    // chunk c + 2 goes into buffer (c + 2) % 3 (last read in step c - 1, a barrier ago); chunk c + 4 is requested; the first
+    // k-block of chunk c + 1 is read; ONE barrier.  With three buffers the first LDS reads of a chunk are issued BEFORE the
+    // barrier that ends the previous step, not after it.  Chunk indices past the end are clamped (re-read, never multiplied).
+    auto cl = [&](int c) { return c < last ? c : last; };
+    f32x4 an[MT];
+    auto step = [&](int c, int buf, const f32x4 (&b)[4], XRegs &x) {
+        f32x4 a0[MT], a1[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a0[m] = an[m];
+#pragma unroll
+        for (int kb = 0; kb < 4; kb += 2) {
+            read_a(buf, kb + 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][sx], b[kb][sx], acc[m], 0, 0, 0);
+            if (kb + 2 < 4) read_a(buf, kb + 2, a0);
+            else {
+                const int b2 = buf >= 1 ? buf - 1 : 2;                 // (c + 2) % 3
+                if constexpr (!(LAB & 2)) {
+                    store_x(cl(c + 2), b2, x);
+                    load_x(cl(c + 4), x);
+                }
+                read_a(buf == 2 ? 0 : buf + 1, 0, an);                 // chunk c + 1, written a step ago
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][sx], b[kb + 1][sx], acc[m], 0, 0, 0);
+        }
+    };
+    load_x(0, x0);
+    load_b(0, b0);
+    load_x(cl(1), x1);
+    load_b(cl(1), b1);
+    store_x(0, 0, x0);
+    load_x(cl(2), x0);
+    store_x(cl(1), 1, x1);
+    load_x(cl(3), x1);
+    __syncthreads();
+    read_a(0, 0, an);
+    int buf = 0;
+    int c = 0;
+    for (; c + 1 < n_chunks; c += 2) {
+        step(c, buf, b0, x0);
+        if constexpr (!(LAB & 4)) load_b(cl(c + 2), b0);
+        if constexpr (!(LAB & 1)) __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
+        step(c + 1, buf, b1, x1);
+        if constexpr (!(LAB & 4)) load_b(cl(c + 3), b1);
+        if constexpr (!(LAB & 1)) __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (c < n_chunks) step(c, buf, b0, x0);
+    // ---- epilogue: bias, LeakyReLU, dropout; the activated value goes to both outputs (row_scale_kernel finishes `norm`)
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const int col = ct * 32 + li;
+    const float bz = bias2[col];
+    if (col >= d_out) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t grow = row0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (grow >= n_rows) continue;
+            float v = acc[m][r] + bz;
+            v = v >= 0.f ? v : leaky * v;
+            if (drop_mask) v *= drop_mask[grow * ldm + col];          // "reference" mode: the noise tensor nn.Dropout drew, NGCF.py:142
+            else if (drop_p > 0.f) {
+                const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                v = h < drop_thr ? 0.f : v * keep_scale;
+            }
+            if (carry) carry[grow * ldc + col] = v;
+            norm[grow * ldn + col] = v;
+        }
+}
+
+// norm[row, :] /= max(||norm[row, :]||, 1e-12) (F.normalize, NGCF.py:144), one wave per row.  The squares are added exactly as
+// the dense kernels add them: per panel of 128 columns lane li takes columns li, 32 + li, 64 + li, 96 + li in that order (fma
+// chain from 0), the 32 lanes are combined by the xor butterfly 1, 2, 4, 8, 16, and the panel sums are added in panel order.
+template <int CW>      // panels: 2 (<= 256 columns) or 4
+__global__ __launch_bounds__(256) void row_scale_kernel(float *__restrict__ norm, int64_t ldn, int64_t n_rows, int d_out)
+{
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    float *x = norm + row * ldn;
+    constexpr int PP = CW / 2;                     // panels per lane half: half h takes panels h, h + 2
+    float v[PP][4], part[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        const int cw = half + 2 * p;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = cw * 128 + t * 32 + li;
+            v[p][t] = col < d_out ? x[col] : 0.f;
+            s = fmaf(v[p][t], v[p][t], s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        part[p] = s;
+    }
+    // panel order 0, 1, 2, 3: this half holds panels half, half + 2, the other one the rest
+    float other[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) other[p] = __shfl_xor(part[p], 32);
+    float ss = 0.f;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        const float even = half == 0 ? part[p] : other[p], odd = half == 0 ? other[p] : part[p];
+        ss += even;
+        ss += odd;
+    }
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int p = 0; p < PP; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = (half + 2 * p) * 128 + t * 32 + li;
+            if (col < d_out) x[col] = v[p][t] * inv;
+        }
+}
+
 static int dense_dop(int d_out)
 {
     if (d_out <= 32) return 32;
@@ -1067,6 +1315,43 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
     const int direct_env = ngcf_opts().dense_direct;
     const bool direct = direct_env && dop >= 256 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
                         n_rows > 0 && (n_rows <= 8192 || direct_env == 2);
+    // 256 / 512 output columns as 96-row x 128-column workgroups, three row tiles per wave, the row norm in a second kernel
+    // (layer_dense_tall_kernel): 248 workgroups for the Seoul graph's 5 940 rows where the direct kernel has 186.  Measured
+    // (tools/dense_wide_lab.py, profiles/r03_dense_wide_lab.txt; tall / direct / staged, us incl. pack and row scale):
+    //   512 columns: 5 940 rows 84 / 92 / 109; 6 144: 84 / 93 / 109; 7 000: 127 / 89 / 107 (a second round of workgroups; the direct
+    //   kernel still has one per CU up to 8 192 rows); 9 000: 132 / 267 / 165; 100 K: 956 / 1 384 / 1 078; 1.1 M: 10 129 / 12 114 / 10 858
+    //   256 columns: 5 940 rows 47 / 47 / 58 (124 workgroups: no gain); 9 000: 48 / 78 / 59; 100 K: 290 / 418 / 310; 200 K: 569 / 735 / 552
+    // dense_tall = 0: never; 2: wherever the shape allows; 1: by these numbers.
+    const int tall_env = ngcf_opts().dense_tall;
+    const bool tall_pays = dop == 512 ? (n_rows <= 6144 || n_rows > 8192) : (n_rows > 8192 && n_rows <= 131072);
+    if (tall_env && dop >= 256 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 && n_rows > 0 &&
+        (tall_pays || tall_env == 2)) {
+        const int n_ct = dop / 32;
+        pack_weights_tall_kernel<<<dim3((unsigned)(n_chunks * n_ct)), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, dop, Wt, bias2);
+        LAUNCH_CHECK();
+        const int64_t groups = (n_rows + kTallRows - 1) / kTallRows;
+#define NGCF_TALL(L) \
+    layer_dense_tall_kernel<L><<<dim3((unsigned)(groups * (n_ct / 4))), 256, 0, stream>>>( \
+        LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, n_chunks, n_ct, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc, norm, ldn)
+#ifdef NGCF_LAB
+        switch (ngcf_opts().dense_il_lab) {
+        case 1: NGCF_TALL(1); break;
+        case 2: NGCF_TALL(2); break;
+        case 3: NGCF_TALL(3); break;
+        case 4: NGCF_TALL(4); break;
+        case 7: NGCF_TALL(7); break;
+        default: NGCF_TALL(0); break;
+        }
+#else
+        NGCF_TALL(0);
+#endif
+#undef NGCF_TALL
+        LAUNCH_CHECK();
+        if (dop == 256) row_scale_kernel<2><<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(norm, ldn, n_rows, d_out);
+        else row_scale_kernel<4><<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(norm, ldn, n_rows, d_out);
+        LAUNCH_CHECK();
+        return NGCF_OK;
+    }
     pack_weights_kernel<<<dim3((unsigned)(n_chunks * (dop / 32))), 256, 0, stream>>>(W1, b1, W2, b2, d_in, d_out, n_chunks, dop,
                                                                                     small_rows ? 1 : dop <= 128 ? dop / 32 : 4, Wt, bias2);
     LAUNCH_CHECK();

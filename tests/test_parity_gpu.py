@@ -895,8 +895,9 @@ def test_resident_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, m
                                               (130, 200, 1000, "last"), (260, 300, 33, "eval"), (8, 512, 64, "hash"),
                                               (256, 256, 40_003, "eval")])
 def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, mode, dev, lib_options):
-    """layer_dense_direct_kernel (256 / 512 output columns, operands straight from global memory, no LDS staging) against
-    layer_dense_kernel on the same inputs: same k order per output element, so carry and normalised block agree bit for bit -
+    """layer_dense_direct_kernel (256 / 512 output columns, operands straight from global memory, no LDS staging) and
+    layer_dense_tall_kernel + row_scale_kernel (96-row x 128-column workgroups, three row tiles per wave, the row norm in a second
+    kernel that adds the squares in the same order) against layer_dense_kernel on the same inputs: same k order per output element, so carry and normalised block agree bit for bit -
     eval mode, hash dropout, host-drawn noise, no carry, output widths below the padded width, partial last tiles."""
     import os
     eng = _pkg().engine
@@ -909,15 +910,16 @@ def test_direct_dense_kernel_is_bit_identical_to_the_staged_one(d_in, d_out, n, 
     mask = (torch.rand((n, d_out), generator=g) > 0.3).float().to(dev) / 0.7 if mode == "mask" else None
     kw = dict(drop_p=0.3 if mode in ("hash", "mask") else 0.0, drop_seed=77 if mode == "hash" else 0, drop_mask=mask)
     outs = []
-    for direct in (2, 0):
-        lib_options(dense_direct=direct)
-        carry = None if mode == "last" else torch.empty((n, d_out), device=dev)
+    for direct, tall in ((2, 0), (0, 0), (0, 2)):           # direct kernel, staged kernel, tall kernel (+ row_scale_kernel)
+        lib_options(dense_direct=direct, dense_tall=tall)
+        carry = None if mode == "last" else torch.full((n, d_out), 5.0, device=dev)
         norm = torch.full((n, d_out + 3), 7.0, device=dev)[:, :d_out]            # a column slice of a wider matrix
         eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, eng.Workspace(), **kw)
         outs.append((carry, norm.clone()))
-    assert torch.equal(outs[0][1], outs[1][1])
+        assert bool((norm.as_strided((n, 3), (d_out + 3, 1), d_out) == 7.0).all())      # nothing written past the slice
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][1], outs[1][1])
     if mode != "last":
-        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[1][0])
     assert float((outs[0][1].norm(dim=1) - 1).abs().max()) < 1e-5
     # and against the plain formula (NGCF.py:131-146, eval mode) on the rows of the first tile
     if mode == "eval":
