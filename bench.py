@@ -356,6 +356,12 @@ def main():
     import seoul_tourism_recommendation_ngcf_amd as pkg
     from seoul_tourism_recommendation_ngcf_amd import _lib, dist as ngcf_dist
     lib = _lib.load()
+    t_start = time.perf_counter()
+
+    def note(msg):          # N > 1: a line per phase on stderr (every rank), so that a slow or failed phase can be found in the logs
+        if world > 1:
+            print(f"[bench rank {rank} +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+    note("process group up")
 
     if args.workload == "c1_train":
         if world != 1:
@@ -424,7 +430,9 @@ def main():
             n = pkg.engine.gather_rows(model.all_items_emb, neg, status)
             return crit(u, p, n)
     else:
+        note("interactions drawn")
         sh = ngcf_dist.ShardedPropagation.from_interactions(model, *inter, mode=args.exchange, device=dev)
+        note(f"sharded propagation ready: transport={sh.backend}" + (f" (p2p fell back: {sh.p2p_error})" if getattr(sh, "p2p_error", None) else ""))
         local_nnz = sh.local_nnz
         spmm_shapes = sh.spmm_shapes()
 
@@ -445,6 +453,7 @@ def main():
         for _ in range(args.warmup):
             last = step_fn()
         barrier()
+        note("warm-up done")
         if prof:
             lib.ngcf_prof_enable(1)                           # hipEvent pair around every SpMM launch
         t0 = time.perf_counter()
@@ -465,6 +474,7 @@ def main():
 
     torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
     dt, loss, n_launch, spmm_ms = timed(step, True)
+    note(f"headline timed: {dt / args.steps * 1e3:.3f} ms per step")
     n_layer = len(layers)
 
     def build_line(dt, loss, n_launch, spmm_ms, sh, spmm_shapes, local_nnz):

@@ -460,6 +460,10 @@ class P2PExchange:
             probe.copy_(torch.arange(n, dtype=torch.float32, device=self.dev) + 1000.0 * self.rank)
             self.publish(63, 1)
             got = torch.empty((self.world, n), dtype=torch.float32, device=self.dev)
+            # `got` may reuse the block of a temporary whose kernels are still queued on this stream (the allocator hands memory
+            # out by stream order): the copies must not land before them.  (Without this fence the self-test failed one run in
+            # three with five ranks on one GPU: a pending kernel of the old owner wrote over the pulled rows.)
+            self.fence()
             for q in self.peers_from(self.rank):
                 self.pull(q, 63, 1, 0, got[q])
                 self.ack(q, 63, 1)
@@ -468,11 +472,17 @@ class P2PExchange:
             want = torch.arange(n, dtype=torch.float32, device=self.dev)[None] + 1000.0 * torch.arange(self.world, device=self.dev)[:, None]
             ok = int(torch.equal(got, want))
             self.wait_acks(63, 1)
-        except Exception:  # noqa: BLE001
+        except Exception as exc:  # noqa: BLE001
             ok = 0
-        t = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend(self.group) == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(int(t.item()))
+            self.last_error = f"rank {self.rank}: {exc!r}"[:300]
+        if ok == 0 and not getattr(self, "last_error", None):
+            self.last_error = f"rank {self.rank}: pulled rows differ from what the peers wrote"
+        errs = [None] * self.world                       # every rank learns what failed where (the bench line quotes it)
+        dist.all_gather_object(errs, getattr(self, "last_error", None) if ok == 0 else None, group=self.group)
+        errs = [e for e in errs if e]
+        if errs:
+            self.last_error = "; ".join(errs)[:600]
+        return not errs
 
     def close_quietly(self):
         try:
@@ -716,7 +726,7 @@ class ShardedPropagation:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         if int(t.item()) == 1 and not ex.selftest():
             t.zero_()
-            self.p2p_error = "self-test failed"
+            self.p2p_error = f"self-test failed ({getattr(ex, 'last_error', None)})"
         if int(t.item()) != 1:                                    # every rank takes the same decision
             if ex is not None:
                 ex.close()
