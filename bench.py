@@ -178,7 +178,7 @@ def cpu_baseline_full(coo, model, n_threads, seed=0):
 TRAIN_CFG = dict(embed=65, layers=(65, 65, 65), node_dropout=0.3, mess_dropout=(0.1, 0.1, 0.1), lr=1e-3, wd=0.025)
 
 
-def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False):
+def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False, auto_graph=True):
     """The reference's training configuration (main.py:63-76 + parsers.py defaults) on the Seoul-shaped stand-in graph, and one
     step of experiment.py:45-58: model(node_flag=True) -> zero_grad -> BPR -> backward -> Adam.step, in train mode, with the
     module's defaults otherwise (index check on)."""
@@ -191,6 +191,7 @@ def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False):
                      [pkg.graphs.to_sparse_coo(x) for x in slices], nd, batch, dev).to(dev)
     model.train()
     model.node_dropout_mode = model.mess_dropout_mode = mode
+    model.auto_train_graph = bool(auto_graph)      # default on: in device mode forward and backward replay two captured graphs from the 2nd call on
     opt = torch.optim.Adam(model.parameters(), lr=c["lr"], capturable=bool(graphed))
     crit = pkg.BPR(c["wd"], batch).to(dev)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
@@ -261,13 +262,14 @@ def cpu_train_baseline(coo_slices_cpu, n_user, model, ids, batch, n_threads, ste
     return dt, float(loss.detach())
 
 
-def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5, graphed=False):
+def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5, graphed=False, auto_graph=True):
     """One labelled measurement of the reference's training step in one dropout mode."""
-    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode, graphed=graphed)
+    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode, graphed=graphed, auto_graph=auto_graph)
     ms, ms_issue, loss = time_train_steps(step, steps, warmup)
     n_layer = len(TRAIN_CFG["layers"])
     return {"ms_per_step": ms, "host_issue_ms_per_step": ms_issue, "value": n_layer * coo["nnz"] / (ms * 1e-3), "unit": "edges/s",
             "loss": loss, "steps": steps, "dropout_mode": mode, "hipgraph": bool(graphed),
+            "forward_backward_graphs": bool(auto_graph and mode == "device" and not graphed),
             "note": f"main.py:63-76 / experiment.py:45-58 on the Seoul-shaped stand-in: embed {TRAIN_CFG['embed']} -> {list(TRAIN_CFG['layers'])}, "
                     f"node dropout {TRAIN_CFG['node_dropout']}, message dropout {list(TRAIN_CFG['mess_dropout'])}, batch {batch}, Adam lr "
                     f"{TRAIN_CFG['lr']}, BPR wd {TRAIN_CFG['wd']}, node_flag=True, train mode; step = forward + BPR + backward + Adam.step; "
@@ -303,6 +305,10 @@ def main_train(args, pkg, dev):
             out["secondary"] = {f"dropout_mode_{other}": train_secondary(pkg, dev, args.batch, other, args.steps, args.warmup)}
         except Exception as exc:  # noqa: BLE001
             out["secondary"] = {f"dropout_mode_{other}": {"error": repr(exc)[:300]}}
+        try:       # device masks, every launch issued by the host (auto_train_graph off)
+            out["secondary"]["device_masks_no_graphs"] = train_secondary(pkg, dev, args.batch, "device", args.steps, args.warmup, auto_graph=False)
+        except Exception as exc:  # noqa: BLE001
+            out["secondary"]["device_masks_no_graphs"] = {"error": repr(exc)[:300]}
         try:       # the step with device masks captured once and replayed (opt-in GraphedTrainStep; Adam(capturable=True))
             out["secondary"]["device_masks_hipgraph"] = train_secondary(pkg, dev, args.batch, "device", max(args.steps, 100), 10, graphed=True)
         except Exception as exc:  # noqa: BLE001

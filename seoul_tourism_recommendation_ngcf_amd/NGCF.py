@@ -21,6 +21,93 @@ from . import engine as _eng
 from .autograd import GatherTriple, propagate_with_grad
 
 
+class _ReplayTrain(torch.autograd.Function):
+    """autograd node of a graph-replayed training forward: forward = replay of the captured forward graph, backward = replay of the
+    captured backward graph; the static gradient buffers are handed to the model's parameters."""
+
+    @staticmethod
+    def forward(ctx, runner, *params):
+        runner.fwd.replay()
+        ctx.runner = runner
+        return tuple(o.detach() for o in runner.outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        r = ctx.runner
+        for s, g in zip(r.gouts, grads):
+            if g is None:
+                s.zero_()
+            elif g.data_ptr() != s.data_ptr():
+                s.copy_(g)
+        # The gradients leave as the graph's own buffers (no copies): with `zero_grad()` between two backward passes (the default
+        # sets `.grad` to None) autograd adopts them and the next replay finds nobody holding them.  A `.grad` that still IS one
+        # of these buffers - gradient accumulation over several backward calls, or `zero_grad(set_to_none=False)` - gets its own
+        # storage first, or the replay would overwrite what it is about to be added to.
+        for p, g in zip(r.params, r.gins):
+            if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                p.grad = p.grad.clone()
+        r.bwd.replay()
+        return (None, *[None if g is None else g.detach() for g in r.gins])
+
+
+class _TrainGraphs:
+    """`NGCF.auto_train_graph`: the eager training forward of one shape and its backward, captured as two hipGraphs that share a
+    memory pool (the pattern of `torch.cuda.make_graphed_callables`, with one difference that matters here: the differentiable
+    inputs of the capture are fresh ALIASES of the parameters - same storage, new leaves.  The parameters themselves carry
+    AccumulateGrad nodes from earlier eager steps for as long as the caller keeps a loss tensor alive, and those belong to the
+    default stream: the captured backward would wait for an event recorded outside the capture, which ends the process on this
+    runtime)."""
+
+    def __init__(self, model, year_idx: int, node_flag: bool, has_neg: bool, args):
+        self.model, self.year_idx, self.node_flag, self.has_neg = model, year_idx, node_flag, has_neg
+        self.flat = torch.cat(args)                                    # static index vectors: views of one buffer (one copy per call)
+        self.idx, o = [], 0
+        for a in args:
+            self.idx.append(self.flat[o:o + a.numel()])
+            o += a.numel()
+        self.params = model._diff_params()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                  # warm-up: everything lazily created exists before the capture
+            for _ in range(3):
+                al = self._aliases()
+                outs = self._body(al)
+                torch.autograd.grad(outs, al, grad_outputs=[torch.empty_like(o) for o in outs], allow_unused=True)
+                del outs, al
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        al = self._aliases()
+        with torch.cuda.graph(self.fwd, pool=pool):
+            outs = self._body(al)
+        self.outs = tuple(outs)
+        self.gouts = tuple(torch.empty_like(o) for o in outs)
+        with torch.cuda.graph(self.bwd, pool=pool):
+            gins = torch.autograd.grad(outs, al, grad_outputs=self.gouts, allow_unused=True)
+        self.gins = tuple(gins)
+
+    def _aliases(self):
+        return [p.detach().requires_grad_(True) for p in self.params]
+
+    def _body(self, aliases):
+        m = self.model
+        saved = (m.check_indices, m._forced_year_idx, m.auto_train_graph, m._alias)
+        m.check_indices, m._forced_year_idx, m.auto_train_graph, m._alias = False, self.year_idx, False, aliases   # no host syncs inside
+        try:
+            u_id, age, sex, month, day, dow, pos = self.idx[:7]
+            neg = self.idx[7] if self.has_neg else torch.empty(0, dtype=torch.int64)
+            u, p, n = NGCF.forward(m, u_id, u_id, age, sex, month, day, dow, pos, neg, self.node_flag)
+        finally:
+            m.check_indices, m._forced_year_idx, m.auto_train_graph, m._alias = saved
+        return (u, p, n) if self.has_neg else (u, p)
+
+    def __call__(self, *args):
+        torch.cat(args, out=self.flat)
+        return _ReplayTrain.apply(self, *self.params)
+
+
 def _spmm_mode() -> int:
     """SpMM kernel choice for the cached Laplacians (include/ngcf_hip.h, ngcf_csr_set_mode); NGCF_SPMM_MODE overrides."""
     return int(os.environ.get("NGCF_SPMM_MODE", "3"))
@@ -108,6 +195,15 @@ class NGCF(nn.Module):
         self._plist = None
         self._year_tag, self._year_idx = None, 0
         self._forced_year_idx = None
+        # Training calls (train mode, autograd on) of launch-bound sizes with both dropouts drawn on the DEVICE: forward and backward
+        # are captured as two hipGraphs on the second call of a shape (`_TrainGraphs`, over the eager path) and
+        # replayed afterwards; `loss.backward()` then replays the backward graph.  Unchanged training loops (experiment.py:45-58) get
+        # a host cost of two graph launches for the model's share of the step.  `auto_train_graph = False` switches it off.
+        self.auto_train_graph = True
+        self._alias = None                       # (capture only) the parameter aliases propagate() differentiates instead of the parameters
+        self._train_graphs = {}                  # key -> graphed core module, most recent last
+        self._train_seen = set()
+        self._train_calls = 0
 
     # ------------------------------------------------------------------------------------
     # engine plumbing
@@ -182,6 +278,12 @@ class NGCF(nn.Module):
         N = self.n_user + self.n_item
         order = torch.sort(idx[1], stable=True).indices          # by column = row of L^T, original order kept inside
         return _eng.LaplacianCSR.from_coo(idx[1][order], idx[0][order], val[order], N, N), order
+
+    def _diff_params(self):
+        """The parameters a training forward differentiates, in the order `_alias` is read: the two embedding tables, then W1, b1,
+        W2, b2 of every layer (the feature tables enter through `.data`, NGCF.py:103-115: no gradient)."""
+        w1, b1, w2, b2 = self._layer_params()
+        return [self.user_embedding.weight, self.item_embedding.weight, *w1, *b1, *w2, *b2]
 
     def _layer_params(self):
         return ([l.weight for l in self.w1_list], [l.bias for l in self.w1_list],
@@ -361,8 +463,12 @@ class NGCF(nn.Module):
             if mess_dev:
                 seeds = [tag(self.n_layer + k) for k in range(self.n_layer)]
         w1, b1, w2, b2 = self._layer_params()
-        all_E = propagate_with_grad(self, csrs, csrs_t_fn, self.user_embedding.weight, self.item_embedding.weight,
-                                    w1, b1, w2, b2, drop, seeds, edge_drops, masks, keep_alive)
+        uw, iw = self.user_embedding.weight, self.item_embedding.weight
+        if self._alias is not None:                                    # _TrainGraphs: same storage, fresh autograd leaves
+            n = self.n_layer
+            uw, iw = self._alias[0], self._alias[1]
+            w1, b1, w2, b2 = (self._alias[2 + j * n:2 + (j + 1) * n] for j in range(4))
+        all_E = propagate_with_grad(self, csrs, csrs_t_fn, uw, iw, w1, b1, w2, b2, drop, seeds, edge_drops, masks, keep_alive)
         self._all_E = all_E
         self.all_users_emb = all_E[:self.n_user, :]                    # NGCF.py:148-149
         self.all_items_emb = all_E[self.n_user:, :]
@@ -385,6 +491,7 @@ class NGCF(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._plist = None
+        self._train_graphs.clear()               # (their static buffers live on the old device / dtype)
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
@@ -443,6 +550,63 @@ class NGCF(nn.Module):
         """Raise IndexError if any graph-replayed forward since the last check saw an out-of-range id."""
         for g in self._graphs.values():
             g.check_status()
+        if self._train_graphs and self._status is not None and int(self._status.item()) != 0:
+            self._status.zero_()
+            raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
+
+    def _train_graph_wanted(self, node_flag, u_id, pos_item, neg_item) -> bool:
+        if not (self.auto_train_graph and self.training and torch.is_grad_enabled() and len(u_id) > 0 and len(pos_item) > 0):
+            return False
+        if len(u_id) + len(pos_item) + len(neg_item) > 8192:            # beyond this GatherTriple.backward sizes its problem on the host
+            return False
+        if (self.n_user + self.n_item) * (self.emb_size + sum(self.weight_size)) * 4 > min(self.auto_graph_max_bytes, 32 << 20):
+            return False                                                # (32 MB: where GatherTriple.backward stays free of host syncs)
+        if node_flag and self.node_dropout and self.node_dropout_mode != "device":
+            return False                                                # reference-mode masks are drawn on the host: nothing to capture
+        if self.mess_dropout is not None and any(float(p) > 0 for p in self.mess_dropout[:self.n_layer]) and self.mess_dropout_mode != "device":
+            return False
+        return not torch.cuda.is_current_stream_capturing()
+
+    def _forward_train_graphed(self, dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag):
+        """The training forward as a hipGraph replay whose autograd node replays the captured backward (module docstring of
+        `auto_train_graph`).  The first call of a shape runs eagerly (its ids are checked at once); the second captures: three
+        warm-up iterations on a side stream, then the two graphs - the dropout seed state is put back afterwards, so the masks of
+        the following steps are exactly those of an eager run.  Parameters are read when the graphs run: optimizer steps and
+        `load_state_dict` need nothing; a replaced parameter tensor gives a new key."""
+        year_idx = self._year_index(year)
+        has_neg = len(neg_item) > 0
+        sizes = (len(u_id), len(pos_item), len(neg_item))
+        for v in (age, sex, month, day, dow):
+            if len(v) != sizes[0]:
+                raise RuntimeError("shape mismatch: feature index vectors and u_id differ in length")
+        key = self._graph_key(dev, sizes, year_idx) + (bool(node_flag), self.node_dropout_mode, self.mess_dropout_mode)
+        to_dev = lambda t: t.to(device=dev, dtype=torch.int64).contiguous()   # noqa: E731
+        args = [to_dev(t) for t in (u_id, age, sex, month, day, dow, pos_item)] + ([to_dev(neg_item)] if has_neg else [])
+        g = self._train_graphs.pop(key, None)
+        if g is None:
+            if key not in self._train_seen:
+                if len(self._train_seen) > 64:
+                    self._train_seen.clear()
+                self._train_seen.add(key)
+                return None
+            for k in list(self._train_graphs)[:max(0, len(self._train_graphs) - 3)]:     # a handful of shapes (full batch, last batch)
+                self._train_graphs.pop(k, None)
+            if getattr(self, "_seed_state", None) is None:
+                self._device_seeds()                                   # (created outside the capture; nothing has drawn from it yet)
+            seed_state = self._seed_state.clone()
+            status = self._status_buf(dev)
+            g = _TrainGraphs(self, year_idx, bool(node_flag), has_neg, args)
+            self._seed_state.copy_(seed_state)                         # the warm-up forwards stepped it
+            if self.check_indices and int(status.item()) != 0:
+                status.zero_()
+                raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
+        self._train_graphs[key] = g
+        self._train_calls += 1
+        outs = g(*args)
+        if self.check_indices and self._train_calls % max(1, int(self.index_check_every)) == 0:
+            self.check_indices_now()
+        outs = [o.clone() for o in outs]                               # fresh tensors like the eager path (the graph's own are overwritten by the next replay)
+        return outs[0], outs[1], (outs[2] if has_neg else torch.empty(0))
 
     def forward(self, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag):
         dev = self._dev()
@@ -456,6 +620,10 @@ class NGCF(nn.Module):
                 len(pos_item) > 0 and (self.n_user + self.n_item) * (self.emb_size + sum(self.weight_size)) * 4 <= self.auto_graph_max_bytes
                 and not torch.cuda.is_current_stream_capturing()):
             out = self._forward_graphed(dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item)
+            if out is not None:
+                return out
+        if self._train_graph_wanted(node_flag, u_id, pos_item, neg_item):
+            out = self._forward_train_graphed(dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag)
             if out is not None:
                 return out
         # feature injection into user_embedding.weight.data, no autograd (NGCF.py:103-115)

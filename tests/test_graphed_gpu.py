@@ -207,3 +207,86 @@ def test_graphed_train_step_replays_the_eager_step(dev):
         assert torch.equal(results[0][1][k], results[1][1][k]), k
     with pytest.raises(RuntimeError, match="capturable"):
         pkg.GraphedTrainStep(model, crit, torch.optim.Adam(model.parameters(), lr=1e-2), batches[0])
+
+
+def test_unchanged_training_loops_get_graph_replays(dev):
+    """NGCF.auto_train_graph: a plain training loop (experiment.py:45-58: forward, zero_grad, BPR, backward, Adam.step) in device
+    dropout mode.  From the second call of a shape on, forward and backward are replays of two captured graphs; the run must be the
+    eager run bit for bit - losses and every parameter after every step - over two batch shapes (full batches and a shorter last
+    batch of an epoch), and an out-of-range id must still raise."""
+    pkg = _pkg()
+    slices = pkg.graphs.seoul_standin(dev, seed=6, n_user=600, n_item=30)
+    lap = [pkg.graphs.to_sparse_coo(s) for s in slices]
+    U, I, B = 600, 30, 96
+    num_dict = {"user": U, "item": I, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    g = torch.Generator().manual_seed(31)
+    epoch = lambda: [_batch(g, B, U, I, dev) for _ in range(3)] + [_batch(g, 40, U, I, dev)]   # noqa: E731
+    batches = epoch() + epoch() + epoch()
+    for b in batches:
+        b["u_id"][:5] = b["u_id"][5:10]                               # duplicates in every batch
+    results = []
+    for auto in (False, True):
+        torch.manual_seed(4)
+        model = pkg.NGCF(65, [65, 65, 65], 0.3, [0.1, 0.1, 0.1], 1.0, lap, num_dict, B, dev).to(dev)
+        model.train()
+        model.node_dropout_mode = model.mess_dropout_mode = "device"
+        model.auto_train_graph = auto
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        crit = pkg.BPR(0.025, B)
+        torch.manual_seed(12)
+        losses, states = [], []
+        for b in batches:
+            u, p, n = model(node_flag=True, **b)
+            opt.zero_grad()
+            loss = crit(u, p, n)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+            states.append(model.w1_list[0].weight.detach().clone())
+        results.append((losses, states, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        assert len(model._train_graphs) == (2 if auto else 0)          # one pair of graphs per batch shape
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    assert len(set(results[0][0])) > 1
+    for a, b_ in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b_)
+    for k in results[0][2]:
+        assert torch.equal(results[0][2][k], results[1][2][k]), k
+    # the last model replays graphs: a bad id is reported (sticky status word, read every index_check_every-th call)
+    model.index_check_every = 1
+    bad = {k: v.clone() for k, v in batches[0].items()}
+    bad["pos_item"][3] = I + 5
+    with pytest.raises(IndexError):
+        model(node_flag=True, **bad)
+    u, p, n = model(node_flag=True, **batches[0])                      # and the model keeps working
+    assert torch.isfinite(u).all()
+    # eval-mode calls in between take the inference path and do not disturb the training graphs
+    model.eval()
+    with torch.no_grad():
+        model(node_flag=False, **batches[1])
+    model.train()
+    u2, p2, n2 = model(node_flag=True, **batches[1])
+    assert u2.requires_grad and torch.isfinite(u2).all()
+    # gradient accumulation over two backward calls without zero_grad, and zero_grad(set_to_none=False): the graph's gradient
+    # buffers must not be what `.grad` accumulates into.  Without dropout the same batch gives the same gradient bit for bit.
+    torch.manual_seed(5)
+    m2 = pkg.NGCF(65, [65, 65], None, None, 1.0, lap, num_dict, B, dev).to(dev)
+    m2.train()
+    m2.node_dropout_mode = m2.mess_dropout_mode = "device"
+    w = m2.w1_list[0].weight
+    grads = []
+    for it in range(4):                                                # calls 0 (eager), 1 (captures), 2, 3 (replays)
+        m2.zero_grad()
+        u, p, n = m2(node_flag=False, **batches[0])
+        crit(u, p, n).backward()
+        grads.append(w.grad.clone())
+    assert len(m2._train_graphs) == 1 and all(torch.equal(grads[0], g_) for g_ in grads[1:])
+    u, p, n = m2(node_flag=False, **batches[0])                        # no zero_grad: accumulate
+    crit(u, p, n).backward()
+    assert torch.equal(w.grad, grads[0] + grads[0])
+    for q in m2.parameters():                                          # zero in place, keep the tensors
+        if q.grad is not None:
+            q.grad.zero_()
+    u, p, n = m2(node_flag=False, **batches[0])
+    crit(u, p, n).backward()
+    assert torch.equal(w.grad, grads[0])
+    assert torch.equal(m2.user_embedding.weight.grad[batches[0]["u_id"][0]], m2.user_embedding.weight.grad[batches[0]["u_id"][0]])
