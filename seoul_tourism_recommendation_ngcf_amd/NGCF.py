@@ -483,7 +483,7 @@ class NGCF(nn.Module):
         if self._plist is None or self._graph_calls % 16 == 0:
             self._plist = list(self.parameters())
         ptrs = tuple(p.data_ptr() for p in self._plist)
-        return (sizes, year_idx, id(self.lap_list[year_idx]), str(dev), ptrs)
+        return (sizes, year_idx, id(self.lap_list[year_idx]), str(dev), ptrs, float(self.emb_ratio))     # (emb_ratio is a kernel argument)
 
     def train(self, mode: bool = True):
         self._plist = None
@@ -579,7 +579,9 @@ class NGCF(nn.Module):
         for v in (age, sex, month, day, dow):
             if len(v) != sizes[0]:
                 raise RuntimeError("shape mismatch: feature index vectors and u_id differ in length")
-        key = self._graph_key(dev, sizes, year_idx) + (bool(node_flag), self.node_dropout_mode, self.mess_dropout_mode)
+        key = self._graph_key(dev, sizes, year_idx) + (      # + everything else a capture bakes into its kernel arguments
+            bool(node_flag), self.node_dropout_mode, self.mess_dropout_mode, self.node_dropout,
+            None if self.mess_dropout is None else tuple(float(x) for x in self.mess_dropout))
         to_dev = lambda t: t.to(device=dev, dtype=torch.int64).contiguous()   # noqa: E731
         args = [to_dev(t) for t in (u_id, age, sex, month, day, dow, pos_item)] + ([to_dev(neg_item)] if has_neg else [])
         g = self._train_graphs.pop(key, None)
