@@ -347,6 +347,9 @@ def main():
     share = os.environ.get("NGCF_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    n_vis = torch.cuda.device_count()
+    if n_vis and local_rank >= n_vis:      # a launcher that shows every rank its own GPU only (HIP_VISIBLE_DEVICES per rank)
+        local_rank %= n_vis
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
