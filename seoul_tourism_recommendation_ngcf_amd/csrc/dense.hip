@@ -543,6 +543,171 @@ __global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident_kernel(
 
 #ifdef NGCF_LAB
 // ---------------------------------------------------------------------------------------------
+// LAB ONLY: layer_dense_resident_kernel with TWO row tiles per wave (64 rows x 128 columns, 128 accumulator registers): a B operand
+// read from LDS feeds eight MFMAs instead of four (half the LDS read bytes per MFMA - MI355X_MICROARCH.md "DVFS give-back": what
+// raises the clock is less energy per MFMA), raw operands one chunk (128 MFMAs) ahead in one register set per tile.  Same k order
+// and epilogue arithmetic: bit-identical.  dense_resident = 3.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kResWaves * 64) void layer_dense_resident2_kernel(
+    const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ Es, int64_t ldE, int64_t n_rows, int d_in, int d_out,
+    const float *__restrict__ Wt, const float *__restrict__ bias2, int n_chunks, float leaky, float drop_p, uint64_t drop_seed_in,
+    const float *__restrict__ drop_mask, int64_t ldm, float *__restrict__ carry, int64_t ldc, float *__restrict__ norm, int64_t ldn)
+{
+    const uint64_t drop_seed = drop_p > 0.f ? resolve_seed(drop_seed_in) : drop_seed_in;
+    constexpr int NT = 4, WCOLS = 128, TP = 2;
+    extern __shared__ float Wres[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Wt);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Wres);
+        const int n4 = n_chunks * NGCF_KC * WCOLS / 4;
+        for (int i = tid; i < n4; i += kResWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t n_pairs = (n_rows + 32 * TP - 1) / (32 * TP);
+    const int d4 = (d_in + 3) & ~3;
+    const float *W = Wres + li * NT + lh * 4 * WCOLS;
+    float bz[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bz[t] = bias2[t * 32 + li];
+    const int last = n_chunks - 1;
+    const int64_t pair_step = (int64_t)gridDim.x * kResWaves;
+    auto row_of = [&](int64_t pr, int u) {
+        int64_t g = pr * (32 * TP) + u * 32 + li;
+        return g < n_rows ? g : n_rows - 1;
+    };
+    auto fetch = [&](const float *le_row, const float *e_row, int c, f32x4 &la, f32x4 &lb, f32x4 &ea, f32x4 &eb) {
+        const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
+        const int cca = ca < d4 ? ca : d4 - 4, ccb = cb < d4 ? cb : d4 - 4;
+        la = *reinterpret_cast<const f32x4 *>(le_row + cca);
+        ea = *reinterpret_cast<const f32x4 *>(e_row + cca);
+        lb = *reinterpret_cast<const f32x4 *>(le_row + ccb);
+        eb = *reinterpret_cast<const f32x4 *>(e_row + ccb);
+    };
+    f32x4 la[TP], lb[TP], ea[TP], eb[TP];
+    int64_t pair = (int64_t)blockIdx.x * kResWaves + wave;
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const int64_t g0 = row_of(pair < n_pairs ? pair : 0, u);
+        fetch(LE + g0 * ldLE, Es + g0 * ldE, 0, la[u], lb[u], ea[u], eb[u]);
+    }
+    for (; pair < n_pairs; pair += pair_step) {
+        const int64_t row0 = pair * (32 * TP);
+        const float *le_row[TP], *e_row[TP];
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            const int64_t g = row_of(pair, u);
+            le_row[u] = LE + g * ldLE, e_row[u] = Es + g * ldE;
+        }
+        f32x16 acc[TP][NT];
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
+        for (int c = 0; c < n_chunks; ++c) {
+            f32x4 a4[TP][4];
+            const int ca = c * NGCF_DC + lh * 4, cb = ca + 8;
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                if (cb + 4 > d_in) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (ca + q >= d_in) la[u][q] = 0.f, ea[u][q] = 0.f;
+                        if (cb + q >= d_in) lb[u][q] = 0.f, eb[u][q] = 0.f;
+                    }
+                }
+                a4[u][0] = la[u] + ea[u], a4[u][1] = lb[u] + eb[u], a4[u][2] = la[u] * ea[u], a4[u][3] = lb[u] * eb[u];
+            }
+            {   // the next chunk - of this pair, or chunk 0 of the wave's next pair (the last pair re-reads its own): unconditional
+                const bool nxt = c == last;
+                const int64_t np = pair + pair_step < n_pairs ? pair + pair_step : pair;
+#pragma unroll
+                for (int u = 0; u < TP; ++u) {
+                    const int64_t gn = row_of(np, u);
+                    const float *lr = nxt ? LE + gn * ldLE : le_row[u], *er = nxt ? Es + gn * ldE : e_row[u];
+                    fetch(lr, er, nxt ? 0 : c + 1, la[u], lb[u], ea[u], eb[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float *wc = W + (int64_t)c * NGCF_KC * WCOLS;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(wc + (kb * 8 + sx) * WCOLS);
+#pragma unroll
+                    for (int u = 0; u < TP; ++u) {
+                        acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.x, acc[u][0], 0, 0, 0);
+                        acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.y, acc[u][1], 0, 0, 0);
+                        acc[u][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.z, acc[u][2], 0, 0, 0);
+                        acc[u][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][kb][sx], bv.w, acc[u][3], 0, 0, 0);
+                    }
+                }
+        }
+        // ---- epilogue per tile (wave-local): bias, LeakyReLU, dropout, row norm, stores
+        const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        const uint32_t drop_thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+#pragma unroll
+        for (int u = 0; u < TP; ++u) {
+            const int64_t t0 = row0 + u * 32;
+            if (t0 >= n_rows) break;
+            float rowss[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rowss[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[u][t][r] + bz[t];
+                    v = v >= 0.f ? v : leaky * v;
+                    if (drop_mask || drop_p > 0.f) {
+                        const int64_t grow = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (drop_mask) v *= (grow < n_rows && col < d_out) ? drop_mask[grow * ldm + col] : 0.f;
+                        else {
+                            const uint32_t h = mix32(drop_seed ^ ((uint64_t)grow * 0x9E3779B97F4A7C15ULL + (uint64_t)col));
+                            v = h < drop_thr ? 0.f : v * keep_scale;
+                        }
+                    }
+                    acc[u][t][r] = v;
+                    rowss[r] = fmaf(v, v, rowss[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s2 = rowss[r];
+                s2 += __shfl_xor(s2, 1);
+                s2 += __shfl_xor(s2, 2);
+                s2 += __shfl_xor(s2, 4);
+                s2 += __shfl_xor(s2, 8);
+                s2 += __shfl_xor(s2, 16);
+                rowss[r] = s2;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t grow = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (grow >= n_rows) continue;
+                const float inv = 1.f / fmaxf(sqrtf(rowss[r]), 1e-12f);   // F.normalize eps, NGCF.py:144
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = t * 32 + li;
+                    if (col < d_out) {
+                        const float v = acc[u][t][r];
+                        if (carry) carry[grow * ldc + col] = v;
+                        norm[grow * ldn + col] = v * inv;
+                    }
+                }
+            }
+        }
+    }
+}
+#endif  // NGCF_LAB
+
+#ifdef NGCF_LAB
+// ---------------------------------------------------------------------------------------------
 // LAB ONLY (-DNGCF_LAB; measured slower than layer_dense_resident_kernel: profiles/r03_dense_il_lab.txt).
 // The resident kernel with the finished tiles leaving UNDER the next tiles' K loop (r03).
 // layer_dense_resident_kernel ends a tile with 128 (256 with a carry) store instructions per wave in one burst and relies on the
@@ -1373,6 +1538,20 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_set[dev_i] = true;
             }
+#ifdef NGCF_LAB
+            if (resident == 3) {
+                static bool r2_set = false;
+                if (!r2_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(layer_dense_resident2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    r2_set = true;
+                }
+                layer_dense_resident2_kernel<<<dim3(kResWGs), kResWaves * 64, (size_t)lds_bytes, stream>>>(
+                    LE, ldLE, Es, ldEs, n_rows, d_in, d_out, Wt, bias2, n_chunks, leaky, drop_p, drop_seed, drop_mask, ld_mask, carry, ldc,
+                    norm, ldn);
+                LAUNCH_CHECK();
+                return NGCF_OK;
+            }
+#endif
 #ifdef NGCF_LAB
             // resident == 2: the finished tile leaves under the next tile's K loop (layer_dense_resident_il_kernel; full 128
             // output columns, 8 or 9 chunks)

@@ -19,7 +19,7 @@ for d_in, d_out, with_carry in ((128, 128, True), (128, 128, False), (130, 128, 
     carry = torch.empty((n, d_out), device=dev) if with_carry else None
     norm = torch.empty((n, d_out), device=dev)
     ref = None
-    for resident in (1, 2, 1, 2):
+    for resident in tuple(int(x) for x in os.environ.get("LAB_VARIANTS", "1,2,1,2").split(",")):   # 3: two tiles per wave (lab)
         _lib.set_option("dense_resident", resident)
         f = lambda: eng.layer_dense(LE, E, W1, b1, W2, b2, carry, norm, ws)
         for _ in range(3):
