@@ -597,14 +597,16 @@ class NGCF(nn.Module):
                 self._device_seeds()                                   # (created outside the capture; nothing has drawn from it yet)
             seed_state = self._seed_state.clone()
             status = self._status_buf(dev)
-            g = _TrainGraphs(self, year_idx, bool(node_flag), has_neg, args)
+            with _eng._on(dev):                                        # (streams and graphs belong to the model's device)
+                g = _TrainGraphs(self, year_idx, bool(node_flag), has_neg, args)
             self._seed_state.copy_(seed_state)                         # the warm-up forwards stepped it
             if self.check_indices and int(status.item()) != 0:
                 status.zero_()
                 raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
         self._train_graphs[key] = g
         self._train_calls += 1
-        outs = g(*args)
+        with _eng._on(dev):
+            outs = g(*args)
         if self.check_indices and self._train_calls % max(1, int(self.index_check_every)) == 0:
             self.check_indices_now()
         outs = [o.clone() for o in outs]                               # fresh tensors like the eager path (the graph's own are overwritten by the next replay)
