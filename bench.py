@@ -192,7 +192,8 @@ def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False, auto_grap
     model.train()
     model.node_dropout_mode = model.mess_dropout_mode = mode
     model.auto_train_graph = bool(auto_graph)      # default on: in device mode forward and backward replay two captured graphs from the 2nd call on
-    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], capturable=bool(graphed))
+    fused = os.environ.get("NGCF_BENCH_ADAM_FUSED") == "1"        # lab: torch's fused Adam (one launch) instead of the reference's default
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], capturable=bool(graphed), **({"fused": True} if fused else {}))
     crit = pkg.BPR(c["wd"], batch).to(dev)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     ids = {k: torch.randint(0, hi, (batch,), generator=g).to(dev)
