@@ -43,7 +43,7 @@ const char *ngcf_last_error(void);
 const char *ngcf_target_arch(void);
 /* ABI version of this header.  ngcf_version() returns the value the library was built with; the Python mirror refuses to bind
  * a library whose version differs (a stale .so would otherwise receive shifted arguments). */
-#define NGCF_ABI_VERSION 5
+#define NGCF_ABI_VERSION 6
 int ngcf_version(void);
 
 /* Tunables of the kernel dispatch (thresholds, lab switches).  The library reads its NGCF_* environment variables ONCE, in
@@ -214,6 +214,11 @@ int ngcf_copy_rows_f32(const float *src, int64_t lds, float *dst, int64_t ldd, i
 int ngcf_copy_rows2_f32(const float *src, int64_t lds, float *dst, int64_t ldd, float *dst2, int64_t ldd2,
                         int64_t n_rows, int d, void *stream);
 
+/* dst[idx[b], 0:d] = src[idx[b], 0:d] for b < n_idx, ids outside [0, n_rows) skipped (r04): block 0 of a retained all_E follows
+ * the rows the feature injection rewrote (NGCF.py:114-115) without the whole table being copied again.  idx: int64, device. */
+int ngcf_copy_rows_indexed_f32(const float *src, int64_t lds, float *dst, int64_t ldd, const int64_t *idx, int64_t n_idx,
+                               int64_t n_rows, int d, void *stream);
+
 /* ---- feature injection (NGCF.py:103-115) ---------------------------------------------- */
 /*
  * user_w[u_id[b], :] = user_w[u_id[b], :]*(1-r) + cat(age,sex,month,day,dow rows)[b, :]*r.
@@ -276,9 +281,11 @@ int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p, int64_t Bp
  * of all_E in a fixed order: out[r, :] = sum of g[order[j], :] for j in [segptr[r], segptr[r+1]), in that order (`order`: the
  * gathered positions sorted by row, stable - duplicates add up in batch order; int64 device arrays).  No atomics. */
 int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr, int64_t n_seg,
-                              const int64_t *dst_rows, const int64_t *n_seg_dev, float *out, int64_t ldo, void *stream);
+                              const int64_t *dst_rows, const int64_t *n_seg_dev, float *out, int64_t ldo, int64_t n_out_rows,
+                              void *stream);
 /* (dst_rows != NULL: the sum of segment r goes to row dst_rows[r] of `out` - the scatter into a dense, zero-filled gradient of
- * all_E; n_seg_dev != NULL: only the first *n_seg_dev segments exist (the count ngcf_rows_sort_unique left on the device: no
+ * all_E with n_out_rows rows; a segment whose destination lies outside [0, n_out_rows) is skipped (r04: memory-safe whatever the
+ * caller's index-check cadence); n_seg_dev != NULL: only the first *n_seg_dev segments exist (the count ngcf_rows_sort_unique left on the device: no
  * host round trip between the two launches), n_seg is then an upper bound that sizes the grid) */
 /* The distinct rows among M <= 8 192 gathered positions, in one launch: idx int64[M] (rows of all_E, each < 2^50) ->
  * order int64[M] (the positions 0..M-1 sorted by row, equal rows in batch order), rows int64[<= M] (distinct, ascending),
@@ -286,7 +293,9 @@ int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t 
  * Feeds ngcf_segment_sum_rows_f32; replaces torch.unique + sort + cumsum (a dozen library launches) on the training step. */
 int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t max_row, int64_t *order, int64_t *rows, int64_t *segptr,
                           int64_t *n_rows, void *stream);
-/* (max_row: an upper bound of the values in idx, or -1 = unknown: below 2^19 the sort runs on 32-bit keys) */
+/* (max_row: the largest valid row, or -1 = unknown / unchecked: below 2^19 the sort runs on 32-bit keys.  r04: with max_row >= 0 an id
+ * outside [0, max_row] - which the forward gather clamped and flagged in its status word - is sorted as ONE sentinel row
+ * max_row + 1 behind the valid ones, forms the last segment of `order` and is not counted in n_rows.) */
 /* Backward of normalise + dropout + LeakyReLU (NGCF.py:140-144): dM from dN (gradient of the all_E block; NULL = zero:
  * the rows no gather touched), dC (gradient of the carry from the next layer, may be NULL; not both) and the saved carry C. */
 int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float *dC, int64_t ldc, const float *C, int64_t ldC,

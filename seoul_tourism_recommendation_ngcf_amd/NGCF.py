@@ -11,6 +11,7 @@ with the module on the CPU raises.
 from __future__ import annotations
 
 import os
+import warnings
 import weakref
 from typing import List, Optional
 
@@ -18,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as _eng
-from .autograd import GatherTriple, propagate_with_grad
+from .autograd import E0Cache, GatherTriple, propagate_with_grad
 
 
 class _ReplayTrain(torch.autograd.Function):
@@ -29,11 +30,21 @@ class _ReplayTrain(torch.autograd.Function):
     def forward(ctx, runner, *params):
         runner.fwd.replay()
         ctx.runner = runner
+        # The saved activations live in the graphs' static pool and are shared by every replay: while this node can still run its
+        # backward, a second replay would overwrite what that backward needs.  The token dies with the node (the caller dropped
+        # the loss without a backward) and is dropped when the backward has run; `_TrainGraphs.outstanding()` reads it.
+        ctx.token = _Token()
+        runner.pending = weakref.ref(ctx.token)
         return tuple(o.detach() for o in runner.outs)
 
     @staticmethod
     def backward(ctx, *grads):
         r = ctx.runner
+        if ctx.token is None or r.pending is None or r.pending() is not ctx.token:
+            raise RuntimeError("NGCF: this training forward was replayed from a captured graph and its saved activations have been "
+                               "overwritten (a second backward through the same forward, or a replay forced in between); set "
+                               "model.auto_train_graph = False for such loops")
+        ctx.token, r.pending = None, None
         for s, g in zip(r.gouts, grads):
             if g is None:
                 s.zero_()
@@ -48,6 +59,11 @@ class _ReplayTrain(torch.autograd.Function):
                 p.grad = p.grad.clone()
         r.bwd.replay()
         return (None, *[None if g is None else g.detach() for g in r.gins])
+
+
+class _Token:
+    """(weak-referenceable marker of an outstanding replayed forward)"""
+    __slots__ = ("__weakref__",)
 
 
 class _TrainGraphs:
@@ -66,27 +82,57 @@ class _TrainGraphs:
             self.idx.append(self.flat[o:o + a.numel()])
             o += a.numel()
         self.params = model._diff_params()
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                                  # warm-up: everything lazily created exists before the capture
-            for _ in range(3):
-                al = self._aliases()
+        self.pending = None
+        # Both graphs bake in the addresses of everything their kernels touch.  The workspace is this object's own (the module's
+        # grow-only one is re-allocated when an eager call asks for more - the other year slice, a larger batch - and the old block
+        # goes back to the allocator); the module's scratch / status / seed-state tensors are long-lived, referenced here so that
+        # their memory cannot be handed out again, and compared before every replay (`intact`).
+        self.ws = _eng.Workspace()
+        uw = model.user_embedding.weight.data
+        rows_before = uw[self.idx[0].clamp(0, model.n_user - 1)].clone()   # the warm-up forwards inject for real (NGCF.py:114): undone below
+        saved_ws, model._ws = model._ws, self.ws
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                              # warm-up: everything lazily created exists before the capture
+                for _ in range(3):
+                    al = self._aliases()
+                    outs = self._body(al)
+                    torch.autograd.grad(outs, al, grad_outputs=[torch.empty_like(o) for o in outs], allow_unused=True)
+                    del outs, al
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            al = self._aliases()
+            with torch.cuda.graph(self.fwd, pool=pool):
                 outs = self._body(al)
-                torch.autograd.grad(outs, al, grad_outputs=[torch.empty_like(o) for o in outs], allow_unused=True)
-                del outs, al
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        pool = torch.cuda.graph_pool_handle()
-        self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        al = self._aliases()
-        with torch.cuda.graph(self.fwd, pool=pool):
-            outs = self._body(al)
-        self.outs = tuple(outs)
-        self.gouts = tuple(torch.empty_like(o) for o in outs)
-        with torch.cuda.graph(self.bwd, pool=pool):
-            gins = torch.autograd.grad(outs, al, grad_outputs=self.gouts, allow_unused=True)
-        self.gins = tuple(gins)
+            self.outs = tuple(outs)
+            self.all_E = model._all_E.detach()                         # the capture's all_E: what the module's attributes alias after a replay
+            self.gouts = tuple(torch.empty_like(o) for o in outs)
+            with torch.cuda.graph(self.bwd, pool=pool):
+                gins = torch.autograd.grad(outs, al, grad_outputs=self.gouts, allow_unused=True)
+            self.gins = tuple(gins)
+        finally:
+            model._ws = saved_ws
+        # emb_ratio != 1: the injection blends (w <- w (1-r) + feats r) and is not idempotent - the three warm-up forwards must not
+        # count, or the batch's user rows would be blended four times by the time of the first replay
+        uw[self.idx[0].clamp(0, model.n_user - 1)] = rows_before
+        self._keep = (self.ws.buf, model._scratch, model._status, getattr(model, "_seed_state", None))
+        self._baked = self._pointers()
+
+    def _pointers(self):
+        m = self.model
+        return tuple(None if t is None else t.data_ptr() for t in (self.ws.buf, m._scratch, m._status, getattr(m, "_seed_state", None)))
+
+    def intact(self) -> bool:
+        """Every buffer whose address the two graphs bake in is still the tensor it was at capture."""
+        return self._pointers() == self._baked
+
+    def outstanding(self) -> bool:
+        """A forward replayed from these graphs can still run its backward (its saved activations must not be overwritten)."""
+        return self.pending is not None and self.pending() is not None
 
     def _aliases(self):
         return [p.detach().requires_grad_(True) for p in self.params]
@@ -105,7 +151,12 @@ class _TrainGraphs:
 
     def __call__(self, *args):
         torch.cat(args, out=self.flat)
-        return _ReplayTrain.apply(self, *self.params)
+        outs = _ReplayTrain.apply(self, *self.params)
+        m = self.model
+        m._e0_cache.invalidate()                                       # (the replay injected rows through `.data`)
+        m._all_E = self.all_E                                          # NGCF.py:148-149: the attributes follow the forward that just ran
+        m.all_users_emb, m.all_items_emb = self.all_E[:m.n_user, :], self.all_E[m.n_user:, :]
+        return outs
 
 
 def _spmm_mode() -> int:
@@ -202,8 +253,13 @@ class NGCF(nn.Module):
         self.auto_train_graph = True
         self._alias = None                       # (capture only) the parameter aliases propagate() differentiates instead of the parameters
         self._train_graphs = {}                  # key -> graphed core module, most recent last
-        self._train_seen = set()
+        self._train_seen = {}                    # key -> the stream its first (eager) call ran on
         self._train_calls = 0
+        self._capture_warned = False
+        # Inference forwards keep their all_E and skip the copy of E0 into block 0 while both embedding tables are unchanged and
+        # nobody else holds the previous result (autograd.E0Cache).  `reuse_all_E = False`: a fresh all_E and a full copy per call.
+        self.reuse_all_E = True
+        self._e0_cache = E0Cache()
 
     # ------------------------------------------------------------------------------------
     # engine plumbing
@@ -418,10 +474,15 @@ class NGCF(nn.Module):
         if st is None or st.device != dev or st.numel() != n or self._seed_state_src != src:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("device-mode dropout: run one training forward before capturing (the seed state is created on first use)")
-            self._seed_state = torch.tensor(self._private_seeds(n), dtype=torch.int64, device=dev)
+            fresh = torch.tensor(self._private_seeds(n), dtype=torch.int64, device=dev)
+            if st is not None and st.device == dev and st.numel() == n:
+                st.copy_(fresh)                  # re-seeded (torch.manual_seed): in place - captured graphs bake this tensor's address in
+            else:
+                self._seed_state = fresh
             self._seed_state_src = src
         else:
-            _eng._lib.check(_eng._lib.load().ngcf_seeds_advance(_eng._ptr(self._seed_state), n, _eng._stream()))
+            with _eng._on(dev):                  # (the launch stream must be the MODEL's device's, whatever device is current)
+                _eng._lib.check(_eng._lib.load().ngcf_seeds_advance(_eng._ptr(self._seed_state), n, _eng._stream()))
         return self._seed_state.clone()
 
     # ------------------------------------------------------------------------------------
@@ -492,7 +553,13 @@ class NGCF(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._plist = None
         self._train_graphs.clear()               # (their static buffers live on the old device / dtype)
+        self._e0_cache.invalidate()
         return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_all_E(self):
+        """Forget the retained all_E (`reuse_all_E`): the next inference forward copies E0 in full.  Needed only after a write to an
+        embedding table through `.data` from outside this module (such writes bypass the version counter the cache watches)."""
+        self._e0_cache.invalidate()
 
     def load_state_dict(self, *args, **kwargs):
         self._plist = None
@@ -555,7 +622,11 @@ class NGCF(nn.Module):
             raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
 
     def _train_graph_wanted(self, node_flag, u_id, pos_item, neg_item) -> bool:
-        if not (self.auto_train_graph and self.training and torch.is_grad_enabled() and len(u_id) > 0 and len(pos_item) > 0):
+        """A differentiable forward of a launch-bound size whose random masks (if any) are drawn on the device.  r04: `self.training`
+        is NOT required - the reference's own loop calls `self.model.eval()` at the end of its first epoch and never `train()` again
+        (experiment.py:61,72), so from epoch 2 on it trains in eval mode: autograd on, `node_flag=True` (node dropout still drawn,
+        NGCF.py:124-126), message dropout off (`nn.Dropout` follows eval, NGCF.py:142)."""
+        if not (self.auto_train_graph and torch.is_grad_enabled() and len(u_id) > 0 and len(pos_item) > 0):
             return False
         if len(u_id) + len(pos_item) + len(neg_item) > 8192:            # beyond this GatherTriple.backward sizes its problem on the host
             return False
@@ -563,9 +634,30 @@ class NGCF(nn.Module):
             return False                                                # (32 MB: where GatherTriple.backward stays free of host syncs)
         if node_flag and self.node_dropout and self.node_dropout_mode != "device":
             return False                                                # reference-mode masks are drawn on the host: nothing to capture
-        if self.mess_dropout is not None and any(float(p) > 0 for p in self.mess_dropout[:self.n_layer]) and self.mess_dropout_mode != "device":
+        if (self.training and self.mess_dropout is not None and any(float(p) > 0 for p in self.mess_dropout[:self.n_layer])
+                and self.mess_dropout_mode != "device"):
             return False
+        if not self.user_embedding.weight.requires_grad and not any(p.requires_grad for p in self._diff_params()):
+            return False                                                # nothing to differentiate: the plain forward
         return not torch.cuda.is_current_stream_capturing()
+
+    def _capture_refusal(self, dev, first_stream) -> Optional[str]:
+        """Why the training forward must NOT be captured right now, or None.  A captured backward that depends on anything recorded
+        outside the capture ends the PROCESS on this runtime (SIGSEGV inside hipStreamEndCapture - gpurun_out/r03/gputests29b.log,
+        DESIGN.md 7 - not an exception that could be caught), so everything that could smuggle such a dependency in, or run foreign
+        code inside the capture, keeps the eager path."""
+        for p in self._diff_params():
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                return "a differentiable parameter carries a backward / post-accumulate-grad hook"
+        if self._backward_hooks or self._backward_pre_hooks:
+            return "the module carries a backward hook"
+        if torch.is_anomaly_enabled():
+            return "autograd anomaly mode is on"
+        if torch._C._autograd._top_saved_tensors_default_hooks(True) is not None:
+            return "saved-tensor hooks are active"
+        if torch.cuda.current_stream(dev).cuda_stream != first_stream:
+            return "the current stream is not the one the first (eager) call of this shape ran on"
+        return None
 
     def _forward_train_graphed(self, dev, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag):
         """The training forward as a hipGraph replay whose autograd node replays the captured backward (module docstring of
@@ -581,20 +673,38 @@ class NGCF(nn.Module):
                 raise RuntimeError("shape mismatch: feature index vectors and u_id differ in length")
         key = self._graph_key(dev, sizes, year_idx) + (      # + everything else a capture bakes into its kernel arguments
             bool(node_flag), self.node_dropout_mode, self.mess_dropout_mode, self.node_dropout,
-            None if self.mess_dropout is None else tuple(float(x) for x in self.mess_dropout))
+            None if self.mess_dropout is None else tuple(float(x) for x in self.mess_dropout), bool(self.training))
         to_dev = lambda t: t.to(device=dev, dtype=torch.int64).contiguous()   # noqa: E731
         args = [to_dev(t) for t in (u_id, age, sex, month, day, dow, pos_item)] + ([to_dev(neg_item)] if has_neg else [])
         g = self._train_graphs.pop(key, None)
+        if g is not None and not g.intact():                           # a baked buffer was replaced: these graphs are dead
+            g = None
+        if getattr(self, "_seed_state", None) is not None and self._seed_state_src != torch.initial_seed():
+            if g is not None:
+                self._train_graphs[key] = g
+            return None                                                # re-seeded since the last draw: this call draws eagerly (and re-seeds in place)
+        if g is not None and g.outstanding():
+            self._train_graphs[key] = g
+            return None                                                # an earlier replay still awaits its backward: this forward runs eagerly
         if g is None:
+            cur = torch.cuda.current_stream(dev).cuda_stream
             if key not in self._train_seen:
                 if len(self._train_seen) > 64:
                     self._train_seen.clear()
-                self._train_seen.add(key)
+                self._train_seen[key] = cur
+                return None
+            why = self._capture_refusal(dev, self._train_seen[key])
+            if why is not None:
+                self._train_seen[key] = cur
+                if not self._capture_warned:
+                    self._capture_warned = True
+                    warnings.warn(f"NGCF.auto_train_graph: the training forward is not captured ({why}); it keeps the eager path", stacklevel=3)
                 return None
             for k in list(self._train_graphs)[:max(0, len(self._train_graphs) - 3)]:     # a handful of shapes (full batch, last batch)
                 self._train_graphs.pop(k, None)
             if getattr(self, "_seed_state", None) is None:
                 self._device_seeds()                                   # (created outside the capture; nothing has drawn from it yet)
+            self._scratch_buf(dev)
             seed_state = self._seed_state.clone()
             status = self._status_buf(dev)
             with _eng._on(dev):                                        # (streams and graphs belong to the model's device)
@@ -631,17 +741,18 @@ class NGCF(nn.Module):
             if out is not None:
                 return out
         # feature injection into user_embedding.weight.data, no autograd (NGCF.py:103-115)
+        u_idx = u_id.to(device=dev, dtype=torch.int64).contiguous()
         with torch.no_grad():
             keep = _eng.feature_inject(
                 self.user_embedding.weight.data,
                 (self.age_emb.weight.data, self.sex_emb.weight.data, self.month_emb.weight.data,
                  self.day_emb.weight.data, self.dow_emb.weight.data),
-                (age, sex, month, day, dow), u_id, self.emb_ratio, self._scratch_buf(dev), status)
+                (age, sex, month, day, dow), u_idx, self.emb_ratio, self._scratch_buf(dev), status)
+        self._e0_cache.touch(u_idx)                                    # (a `.data` write: the retained all_E follows these rows)
 
         year_idx = self._year_index(year)                              # == year.unique()[0] % 18, NGCF.py:117
         self.propagate(year_idx, bool(node_flag))
 
-        u_idx = u_id.to(device=dev, dtype=torch.int64).contiguous()
         p_idx = pos_item.to(device=dev, dtype=torch.int64).contiguous()
         n_idx = neg_item.to(device=dev, dtype=torch.int64).contiguous() if len(neg_item) > 0 else None
         neg_i_embeddings = torch.empty(0)                                       # NGCF.py:153

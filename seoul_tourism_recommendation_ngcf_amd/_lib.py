@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be loaded before libngcf_hip.so, see module do
 from . import _build
 
 OK, ERR_ARG, ERR_HIP, ERR_INDEX, ERR_WORKSPACE = 0, 1, 2, 3, 4
-ABI_VERSION = 5          # NGCF_ABI_VERSION of include/ngcf_hip.h these prototypes were written against
+ABI_VERSION = 6          # NGCF_ABI_VERSION of include/ngcf_hip.h these prototypes were written against
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
 
@@ -59,6 +59,7 @@ PROTOTYPES = {
                                        _f32, _f32, _u64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ngcf_copy_rows_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_copy_rows2_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
+    "ngcf_copy_rows_indexed_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _vp]),
     "ngcf_feature_inject_f32": (C.c_int, [_vp, _i64, _i64, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                                           C.POINTER(_i64), C.c_int, _vp, _i64, C.c_double, _vp, _vp, _vp]),
     "ngcf_seeds_advance": (C.c_int, [_vp, C.c_int, _vp]),
@@ -68,7 +69,7 @@ PROTOTYPES = {
     "ngcf_bpr_fused_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _i64, _vp]),
     "ngcf_bpr_backward_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "ngcf_rows_sort_unique": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "ngcf_segment_sum_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "ngcf_segment_sum_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp]),
     "ngcf_layer_bwd_pre_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_int, _f32, _f32, _u64, _vp, _i64,
                                          _vp, _vp, _i64, _vp]),
     "ngcf_spmm_t_rows_f32": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, _vp, _i64, _vp, _i64, _f32, C.POINTER(_u64), C.c_int, _vp, _i64, _vp]),

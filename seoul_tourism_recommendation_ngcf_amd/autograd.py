@@ -9,6 +9,7 @@ GEMM at any width.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import List, Optional, Sequence
 
 import torch
@@ -49,6 +50,84 @@ def _write_e0(owner, user_w, item_w, all_E, U, d0):
     return all_E[:, :d0]
 
 
+class E0Cache:
+    """The all_E of the previous inference forward, kept so that block 0 - E0 = cat(user table, item table), NGCF.py:120 - need not
+    be copied again while the tables are unchanged (r04; SURVEY 2.2 K4: 563 MB through `copy_rows_kernel` per forward at C3, 0.21 ms).
+
+    Re-used only when ALL of this holds, else a fresh all_E is allocated and E0 copied in full, exactly as before:
+      * both tables are the same tensors (address, shape) at the same autograd version counter as when block 0 was written
+        (optimizer steps, `load_state_dict`, `nn.init` and every other in-place op on the Parameter bump it; `.to()` moves it);
+      * nobody but the module holds the old all_E or a view of it: Python reference counts of the tensor and of the module's two
+        views (`all_users_emb`, `all_items_emb`) and the use count of their storage are exactly the module's own - a caller who
+        kept `model.all_items_emb` (demo.py:233) or a slice of it keeps it intact, as with the reference's fresh `cat` per call
+        (copy-on-hold rather than a rotation of buffers).
+    The rows the feature injection rewrites through `.data` (NGCF.py:114-115 - invisible to the version counter, but done by this
+    module's own kernel) are recorded (`touch`) and copied row by row.  What the cache cannot see: a write through `.data` from
+    OUTSIDE the module (`.detach()`-ed aliases share the counter and are seen) - call `model.invalidate_all_E()` after such a
+    write, or set `NGCF.reuse_all_E = False` (INTEGRATION.md)."""
+
+    MAX_TOUCHED = 8            # batches of injected rows remembered; beyond that the next forward copies everything
+
+    def __init__(self):
+        self.all_E, self.tag, self.touched = None, None, []
+
+    def invalidate(self):
+        self.all_E, self.tag, self.touched = None, None, []
+
+    def touch(self, rows: torch.Tensor):
+        """`rows` (int64, device) of the user table were rewritten in place."""
+        if self.all_E is None:
+            return
+        if len(self.touched) >= self.MAX_TOUCHED:
+            self.invalidate()
+        else:
+            self.touched.append(rows)
+
+    @staticmethod
+    def tag_of(user_w, item_w, widths, dev):
+        return (user_w.data_ptr(), int(user_w._version), tuple(user_w.shape), item_w.data_ptr(), int(item_w._version),
+                tuple(item_w.shape), tuple(widths), str(dev))
+
+    def only_the_modules(self, owner) -> bool:
+        """True iff the cached all_E and the module's two views of it are referenced by the module (and this cache) alone."""
+        d = owner.__dict__
+        if d.get("_all_E") is not self.all_E or self.all_E is None:
+            return False
+        # references to the tensor object: this cache, owner._all_E, getrefcount's own argument, and the one the C++ side keeps
+        # on the Python object of a tensor that has views (measured, torch 2.10; a count that differs only ever costs the copy)
+        if sys.getrefcount(self.all_E) != 4:
+            return False
+        for name in ("all_users_emb", "all_items_emb"):
+            if d.get(name) is None or d[name]._base is not self.all_E:
+                return False
+            if sys.getrefcount(d[name]) != 2:                      # the module's dict + getrefcount's argument
+                return False
+        # tensors sharing the storage: all_E, the two views (each holds all_E as its `_base` - counted above), the temporary wrapper
+        return torch._C._storage_Use_Count(self.all_E.untyped_storage()._cdata) == 4
+
+
+def _all_E_with_e0(owner, user_w, item_w, N, widths, dev):
+    """(all_E with block 0 = E0 written, E0 as the first layer reads it).  `owner._e0_cache` (NGCF modules; the graph runners
+    have none): see `E0Cache`."""
+    U, d0 = int(user_w.shape[0]), widths[0]
+    cache = getattr(owner, "_e0_cache", None)
+    if cache is not None and getattr(owner, "reuse_all_E", True) and not torch.cuda.is_current_stream_capturing():
+        tag = E0Cache.tag_of(user_w, item_w, widths, dev)
+        if cache.tag == tag and cache.only_the_modules(owner):
+            all_E = cache.all_E
+            for rows in cache.touched:
+                _eng.copy_rows_indexed(user_w.detach(), all_E[:U, :d0], rows)
+            cache.touched = []
+            return all_E, all_E[:, :d0]
+        cache.invalidate()                     # (drops the old block before the new one is allocated)
+        all_E = _alloc_all_E(N, widths, dev)
+        prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
+        cache.all_E, cache.tag = all_E, tag
+        return all_E, prev
+    all_E = _alloc_all_E(N, widths, dev)
+    return all_E, _write_e0(owner, user_w, item_w, all_E, U, d0)
+
+
 def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.Tensor, item_w: torch.Tensor,
                       w1, b1, w2, b2, drop: Sequence[float], seeds: Sequence[int], edge_drops=None, masks=None):
     """all_E [N, D] = [E0 | norm(E1) | ... | norm(En)] (NGCF.py:120-147), inference path.
@@ -63,8 +142,7 @@ def propagate_forward(owner, csrs: Sequence["_eng.LaplacianCSR"], user_w: torch.
     d0 = int(user_w.shape[1])
     n_layer = len(w1)
     widths = [d0] + [int(w.shape[0]) for w in w1]
-    all_E = _alloc_all_E(N, widths, dev)
-    prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
+    all_E, prev = _all_E_with_e0(owner, user_w, item_w, N, widths, dev)
     off = d0
     for k in range(n_layer):
         d_out = widths[k + 1]
@@ -169,6 +247,8 @@ class Propagate(torch.autograd.Function):
         U, I = int(user_w.shape[0]), int(item_w.shape[0])
         N, d0 = U + I, int(user_w.shape[1])
         widths = [d0] + [int(w.shape[0]) for w in w1]
+        if getattr(owner, "_e0_cache", None) is not None:
+            owner._e0_cache.invalidate()       # (the module's all_E is about to be replaced by one this node saves for its backward)
         all_E = _alloc_all_E(N, widths, dev)
         prev = _write_e0(owner, user_w, item_w, all_E, U, d0)
         off = d0
@@ -303,7 +383,7 @@ class GatherTriple(torch.autograd.Function):
             with _eng._on(dev):
                 _lib.check(lib.ngcf_rows_sort_unique(_ptr(pos_all.contiguous()), M, N - 1, _ptr(order), _ptr(rows), _ptr(segptr), _ptr(cnt), _stream()))
                 _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), M, _ptr(rows), _ptr(cnt), _ptr(G), D,
-                                                         _stream()))
+                                                         N, _stream()))
             return (G, None, None, None, None, None)
         if M <= 8192 and N < (1 << 50):
             # one launch: sorted distinct rows, the positions grouped by row in batch order, the group bounds (ngcf_rows_sort_unique)
@@ -321,7 +401,7 @@ class GatherTriple(torch.autograd.Function):
             torch.cumsum(counts, 0, out=segptr[1:])
         vals = torch.empty((R, D), dtype=torch.float32, device=dev)
         with _eng._on(dev):
-            _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), R, None, None, _ptr(vals), D, _stream()))
+            _lib.check(lib.ngcf_segment_sum_rows_f32(_ptr(g_all), D, D, _ptr(order), _ptr(segptr), R, None, None, _ptr(vals), D, 0, _stream()))
         G = torch.sparse_coo_tensor(rows[None], vals, (N, D), is_coalesced=True)
         return (G, None, None, None, None, None)
 

@@ -72,12 +72,16 @@ extern "C" int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p,
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ g, int64_t ldg, int d,
                                                                const int64_t *__restrict__ order, const int64_t *__restrict__ segptr,
                                                                int64_t n_seg, const int64_t *__restrict__ dst_rows,
-                                                               const int64_t *__restrict__ n_seg_dev, float *__restrict__ out, int64_t ldo)
+                                                               const int64_t *__restrict__ n_seg_dev, float *__restrict__ out, int64_t ldo,
+                                                               int64_t n_out_rows)
 {
     int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_seg || (n_seg_dev && r >= *n_seg_dev)) return;       // n_seg_dev: the number of segments lives on the device
     const int64_t j0 = segptr[r], j1 = segptr[r + 1];
-    if (dst_rows) r = dst_rows[r];                                  // scatter form: segment r is row dst_rows[r] of a larger matrix
+    if (dst_rows) {                                                 // scatter form: segment r is row dst_rows[r] of a larger matrix
+        r = dst_rows[r];
+        if (r < 0 || r >= n_out_rows) return;                       // (an id the forward gather clamped and flagged: nothing to add, nothing written)
+    }
     // four chains over the segment (positions j0 + 4 i + q), combined as (s0 + s1) + (s2 + s3): a fixed order whose loads do not
     // wait for each other (a popular item is gathered 20 times in a batch of 1 024 on the Seoul graph's 100 items)
     for (int c = threadIdx.x & 63; c < d; c += 64) {
@@ -97,13 +101,15 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__re
 
 extern "C" int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, const int64_t *order, const int64_t *segptr,
                                          int64_t n_seg, const int64_t *dst_rows, const int64_t *n_seg_dev, float *out, int64_t ldo,
-                                         void *stream_)
+                                         int64_t n_out_rows, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_seg == 0) return NGCF_OK;
     if (!g || !order || !segptr || !out || d <= 0 || ldg < d || ldo < d || n_seg < 0) return fail(NGCF_ERR_ARG, "segment_sum_rows: bad argument");
+    if (dst_rows && n_out_rows <= 0) return fail(NGCF_ERR_ARG, "segment_sum_rows: the scatter form needs the row count of out");
     if ((n_seg + 3) / 4 >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "segment_sum_rows: too many rows");
-    segment_sum_rows_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), 256, 0, stream>>>(g, ldg, d, order, segptr, n_seg, dst_rows, n_seg_dev, out, ldo);
+    segment_sum_rows_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), 256, 0, stream>>>(g, ldg, d, order, segptr, n_seg, dst_rows, n_seg_dev, out, ldo,
+                                                                                   n_out_rows);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -710,9 +716,9 @@ extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, co
 static constexpr int kSortMax = 8192, kSortThreads = 1024;
 
 template <typename K>     // key type: 32 bits when row << 13 | position fits (rows below 2^19: the Seoul graph), else 64
-__global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const int64_t *__restrict__ idx, int M, int64_t *__restrict__ order,
-                                                                        int64_t *__restrict__ rows, int64_t *__restrict__ segptr,
-                                                                        int64_t *__restrict__ n_rows)
+__global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const int64_t *__restrict__ idx, int M, int64_t max_row,
+                                                                        int64_t *__restrict__ order, int64_t *__restrict__ rows,
+                                                                        int64_t *__restrict__ segptr, int64_t *__restrict__ n_rows)
 {
     __shared__ K key[kSortMax];
     __shared__ int wsum[kSortThreads / 64];
@@ -720,8 +726,18 @@ __global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const in
     const int tid = threadIdx.x;
     int P = 64;
     while (P < M) P <<= 1;                                          // power of two >= M
-    for (int i = tid; i < P; i += kSortThreads)
-        key[i] = i < M ? (K)(((K)idx[i] << 13) | (K)i) : (K)~(K)0;
+    // An id outside [0, max_row] (the forward gather clamped it and set the sticky status word; with deferred index checks the
+    // backward may still run) becomes the one sentinel row max_row + 1: it sorts behind every valid row, forms the last segment
+    // and is NOT counted in n_rows - nothing downstream ever indexes all_E with it.
+    for (int i = tid; i < P; i += kSortThreads) {
+        K k = (K)~(K)0;
+        if (i < M) {
+            int64_t r = idx[i];
+            if (max_row >= 0 && (r < 0 || r > max_row)) r = max_row + 1;
+            k = (K)(((K)r << 13) | (K)i);
+        }
+        key[i] = k;
+    }
     __syncthreads();
     // one comparator per thread and pass: pair t exchanges i = (t with a zero bit inserted at log2 j) and i + j.  At j <= 64 the 64
     // pairs of a wave stay inside one 128-key block, so those passes need no workgroup barrier - a wave's LDS operations complete in
@@ -774,7 +790,8 @@ __global__ __launch_bounds__(kSortThreads) void rows_sort_unique_kernel(const in
     }
     if (tid == 0) {
         segptr[carry_s] = M;
-        n_rows[0] = carry_s;
+        const bool sentinel = max_row >= 0 && M > 0 && (int64_t)(key[M - 1] >> 13) == max_row + 1;
+        n_rows[0] = carry_s - (sentinel ? 1 : 0);
     }
 }
 
@@ -783,10 +800,11 @@ extern "C" int ngcf_rows_sort_unique(const int64_t *idx, int64_t M, int64_t max_
 {
     if (M < 0 || M > kSortMax) return fail(NGCF_ERR_ARG, "rows_sort_unique: M=%lld not in [0, %d]", (long long)M, kSortMax);
     if (!order || !rows || !segptr || !n_rows || (M > 0 && !idx)) return fail(NGCF_ERR_ARG, "rows_sort_unique: null argument");
-    if (max_row >= 0 && max_row < ((int64_t)1 << 19) - 1)
-        rows_sort_unique_kernel<unsigned><<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, order, rows, segptr, n_rows);
+    if (max_row >= ((int64_t)1 << 50)) return fail(NGCF_ERR_ARG, "rows_sort_unique: rows must be below 2^50");
+    if (max_row >= 0 && max_row < ((int64_t)1 << 19) - 2)
+        rows_sort_unique_kernel<unsigned><<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, max_row, order, rows, segptr, n_rows);
     else
-        rows_sort_unique_kernel<unsigned long long><<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, order, rows, segptr, n_rows);
+        rows_sort_unique_kernel<unsigned long long><<<1, kSortThreads, 0, (hipStream_t)stream>>>(idx, (int)M, max_row, order, rows, segptr, n_rows);
     LAUNCH_CHECK();
     return NGCF_OK;
 }

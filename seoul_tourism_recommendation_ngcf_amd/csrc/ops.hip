@@ -57,6 +57,32 @@ extern "C" int ngcf_copy_rows2_f32(const float *src, int64_t lds, float *dst, in
     return copy_rows_impl(src, lds, dst, ldd, dst2, ldd2, n_rows, d, (hipStream_t)stream_);
 }
 
+// dst[idx[b], :] = src[idx[b], :] for the rows a batch touched (r04): block 0 of a RETAINED all_E follows the <= B rows the
+// feature injection rewrote (NGCF.py:114) instead of the whole table being copied again (563 MB at C3).  One wave per index;
+// duplicates write the same bits; ids outside [0, n_rows) are skipped (the injection flagged them).
+__global__ __launch_bounds__(256) void copy_rows_indexed_kernel(const float *__restrict__ src, int64_t lds, float *__restrict__ dst,
+                                                                int64_t ldd, const int64_t *__restrict__ idx, int64_t n_idx,
+                                                                int64_t n_rows, int d)
+{
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_idx) return;
+    const int64_t r = idx[b];
+    if (r < 0 || r >= n_rows) return;
+    for (int c = threadIdx.x & 63; c < d; c += 64) dst[r * ldd + c] = src[r * lds + c];
+}
+
+extern "C" int ngcf_copy_rows_indexed_f32(const float *src, int64_t lds, float *dst, int64_t ldd, const int64_t *idx, int64_t n_idx,
+                                          int64_t n_rows, int d, void *stream_)
+{
+    if (!src || !dst || d <= 0 || n_idx < 0 || n_rows < 0 || lds < d || ldd < d || (n_idx > 0 && !idx))
+        return fail(NGCF_ERR_ARG, "copy_rows_indexed: bad argument");
+    if (n_idx == 0 || n_rows == 0) return NGCF_OK;
+    if ((n_idx + 3) / 4 >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "copy_rows_indexed: too many indices");
+    copy_rows_indexed_kernel<<<dim3((unsigned)((n_idx + 3) / 4)), 256, 0, (hipStream_t)stream_>>>(src, lds, dst, ldd, idx, n_idx, n_rows, d);
+    LAUNCH_CHECK();
+    return NGCF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // feature injection, NGCF.py:103-115
 // ---------------------------------------------------------------------------------------------

@@ -335,6 +335,19 @@ def copy_rows(src: torch.Tensor, dst: torch.Tensor, dst2: Optional[torch.Tensor]
                                                src.shape[1], _stream()))
 
 
+def copy_rows_indexed(src: torch.Tensor, dst: torch.Tensor, idx: torch.Tensor):
+    """dst[idx[b], :] = src[idx[b], :] (ngcf_copy_rows_indexed_f32): the rows a batch touched, ids out of range skipped."""
+    lib = _lib.load()
+    _f32c(src, "src"), _f32c(dst, "dst")
+    if src.shape != dst.shape or idx.dtype != torch.int64 or not idx.is_contiguous() or idx.device != dst.device:
+        raise RuntimeError("copy_rows_indexed: src and dst must have one shape, idx must be a contiguous int64 tensor on their device")
+    if idx.numel() == 0 or src.shape[0] == 0:
+        return
+    with _on(dst.device):
+        _lib.check(lib.ngcf_copy_rows_indexed_f32(_ptr(src), _row_major_ld(src, "src"), _ptr(dst), _row_major_ld(dst, "dst"), _ptr(idx),
+                                                  idx.numel(), src.shape[0], src.shape[1], _stream()))
+
+
 def gather_rows(table: torch.Tensor, idx: torch.Tensor, status: torch.Tensor, row_off: int = 0,
                 n_idx_rows: Optional[int] = None) -> torch.Tensor:
     """out[b] = table[row_off + idx[b]] (NGCF.py:151-155), bit-exact copies; fresh output tensor."""

@@ -126,6 +126,7 @@ class GraphedForward:
         self.graph.replay()
         all_E, u, p, n = self.out
         m = self.model
+        m._e0_cache.invalidate()                 # (the replay injected rows through `.data` behind the retained all_E's back)
         m._all_E = all_E
         m.all_users_emb, m.all_items_emb = all_E[:m.n_user], all_E[m.n_user:]       # NGCF.py:148-149
         if check and m.check_indices:
@@ -221,6 +222,7 @@ class GraphedTrainStep:
         self.graph.replay()
         self.steps_done += 1
         m = self.model
+        m._e0_cache.invalidate()
         if m.check_indices and self.steps_done % max(1, int(m.index_check_every)) == 0 and int(self.status.item()) != 0:
             self.status.zero_()
             raise IndexError("index out of range in a graph-replayed training step (u_id / feature ids / pos_item / neg_item)")
