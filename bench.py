@@ -48,6 +48,9 @@ WORKLOADS = {
     # stand-in: embed 65 -> [65, 65, 65], node dropout 0.3, message dropout [0.1]*3, batch 1024, Adam lr 1e-3, BPR wd 0.025,
     # node_flag=True, model.train(); one step = forward + BPR + backward + optimizer step
     "c1_train": (5840, 100, 0, 65, (65, 65, 65), 1801),
+    # the TRAINING step at scale (experiment.py:45-58 on C3's graph): embed 130 -> [128]*3 (the reference-legal width next to d = 128),
+    # node dropout 0.3 and message dropout 0.1 drawn on the device, batch 1024, Adam; step = forward + BPR + backward + optimizer step
+    "c3_train": (1_000_000, 100_000, 50_000_000, 130, (128, 128, 128), 2603),
 }
 
 
@@ -178,7 +181,7 @@ def cpu_baseline_full(coo, model, n_threads, seed=0):
 TRAIN_CFG = dict(embed=65, layers=(65, 65, 65), node_dropout=0.3, mess_dropout=(0.1, 0.1, 0.1), lr=1e-3, wd=0.025)
 
 
-def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False, auto_graph=True):
+def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False, auto_graph=True, eval_mode=False):
     """The reference's training configuration (main.py:63-76 + parsers.py defaults) on the Seoul-shaped stand-in graph, and one
     step of experiment.py:45-58: model(node_flag=True) -> zero_grad -> BPR -> backward -> Adam.step, in train mode, with the
     module's defaults otherwise (index check on)."""
@@ -189,7 +192,7 @@ def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False, auto_grap
     c = TRAIN_CFG
     model = pkg.NGCF(c["embed"], list(c["layers"]), c["node_dropout"], list(c["mess_dropout"]), 1.0,
                      [pkg.graphs.to_sparse_coo(x) for x in slices], nd, batch, dev).to(dev)
-    model.train()
+    model.train(not eval_mode)       # eval_mode: the reference's loop from its 2nd epoch on (experiment.py:61,72: eval() is never undone)
     model.node_dropout_mode = model.mess_dropout_mode = mode
     model.auto_train_graph = bool(auto_graph)      # default on: in device mode forward and backward replay two captured graphs from the 2nd call on
     fused = os.environ.get("NGCF_BENCH_ADAM_FUSED") == "1"        # lab: torch's fused Adam (one launch) instead of the reference's default
@@ -263,14 +266,15 @@ def cpu_train_baseline(coo_slices_cpu, n_user, model, ids, batch, n_threads, ste
     return dt, float(loss.detach())
 
 
-def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5, graphed=False, auto_graph=True):
+def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5, graphed=False, auto_graph=True, eval_mode=False):
     """One labelled measurement of the reference's training step in one dropout mode."""
-    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode, graphed=graphed, auto_graph=auto_graph)
+    model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode, graphed=graphed, auto_graph=auto_graph, eval_mode=eval_mode)
     ms, ms_issue, loss = time_train_steps(step, steps, warmup)
     n_layer = len(TRAIN_CFG["layers"])
     return {"ms_per_step": ms, "host_issue_ms_per_step": ms_issue, "value": n_layer * coo["nnz"] / (ms * 1e-3), "unit": "edges/s",
             "loss": loss, "steps": steps, "dropout_mode": mode, "hipgraph": bool(graphed),
-            "forward_backward_graphs": bool(auto_graph and mode == "device" and not graphed),
+            "model_mode": "eval (experiment.py:61,72: the loop's steady state from epoch 2 on; message dropout off, node dropout on)" if eval_mode else "train",
+            "forward_backward_graphs": bool(auto_graph and mode == "device" and not graphed and len(model._train_graphs) > 0),
             "note": f"main.py:63-76 / experiment.py:45-58 on the Seoul-shaped stand-in: embed {TRAIN_CFG['embed']} -> {list(TRAIN_CFG['layers'])}, "
                     f"node dropout {TRAIN_CFG['node_dropout']}, message dropout {list(TRAIN_CFG['mess_dropout'])}, batch {batch}, Adam lr "
                     f"{TRAIN_CFG['lr']}, BPR wd {TRAIN_CFG['wd']}, node_flag=True, train mode; step = forward + BPR + backward + Adam.step; "
@@ -330,6 +334,153 @@ def main_train(args, pkg, dev):
     print(json.dumps(out), flush=True)
 
 
+def timed_blocks(fn, blocks=5, steps=40, warmup=20):
+    """`blocks` x `steps` calls of fn, each block between two synchronisations: (median, min, max) ms per step over the blocks.
+    One block of 200 steps turns a single host-side stall (a full Python garbage collection is tens of milliseconds in a process
+    with torch loaded) into +0.15 ms per step; the median of five blocks does not, and the collector is off while a block runs."""
+    import gc
+    for _ in range(warmup):
+        last = fn()
+    torch.cuda.synchronize()
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    per = []
+    try:
+        for _ in range(blocks):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                last = fn()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / steps * 1e3)
+    finally:
+        if was:
+            gc.enable()
+    return sorted(per)[len(per) // 2], min(per), max(per), per, last
+
+
+C3_TRAIN_CFG = dict(node_dropout=0.3, mess_dropout=(0.1, 0.1, 0.1), lr=1e-3, wd=0.025)
+
+
+def c3_train_measure(pkg, lib, dev, lap, n_user, n_item, nnz, batch, steps, warmup, seed=2603):
+    """The training step at scale: experiment.py:45-58 on the C3 graph at embed 130 -> [128]*3, node dropout 0.3 + message dropout
+    0.1 drawn on the device (the reference-mode masks are ~100 M CPU-generator draws per layer: minutes per step on any host),
+    batch 1024, torch.optim.Adam over all parameters; step = forward + BPR + backward + optimizer step.  Returns a dict with the
+    step time and the live mean duration of one SpMM product (forward L.E and backward L^T.dLE alike: L is symmetric)."""
+    import ctypes as C
+    from seoul_tourism_recommendation_ngcf_amd import _lib
+    _, _, _, d0, layers, _ = WORKLOADS["c3_train"]
+    c = C3_TRAIN_CFG
+    nd = {"user": n_user, "item": n_item, "sex": 2, "age": 76, "month": 13, "day": 32, "dayofweek": 7}
+    torch.manual_seed(seed)
+    model = pkg.NGCF(d0, list(layers), c["node_dropout"], list(c["mess_dropout"]), 1.0, [lap], nd, batch, dev).to(dev).train()
+    model.check_indices = False
+    model.node_dropout_mode = model.mess_dropout_mode = "device"
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"])
+    crit = pkg.BPR(c["wd"], batch)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    ids = {k: torch.randint(0, hi, (batch,), generator=g).to(dev)
+           for k, hi in (("u_id", n_user), ("pos_item", n_item), ("neg_item", n_item), ("age", 76), ("sex", 2), ("month", 13), ("day", 32), ("dow", 7))}
+    ids["year"] = torch.full((batch,), 18, device=dev)
+
+    def step():
+        u, p, n = model(node_flag=True, **ids)
+        opt.zero_grad()
+        loss = crit(u, p, n)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    lib.ngcf_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    n_l, tot = C.c_int64(), C.c_double()
+    _lib.check(lib.ngcf_prof_collect(C.byref(n_l), C.byref(tot)))
+    lib.ngcf_prof_enable(0)
+    assert torch.isfinite(loss).item(), "non-finite loss"
+    csr = model.laplacian_csr(0)
+    N = n_user + n_item
+    return {"ms_per_step": ms, "value": len(layers) * nnz / (ms * 1e-3), "unit": "edges/s", "loss": float(loss), "steps": steps,
+            "spmm_products_timed": int(n_l.value), "spmm_products_per_step": n_l.value / max(steps, 1),
+            "mean_spmm_product_ms": tot.value / max(n_l.value, 1),
+            "spmm_model_a_bytes": {str(d): spmm_model_a_bytes(csr.nnz, N, N, d) for d in sorted({d0, *layers})},
+            "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30, "model": model, "ids": ids, "d0": d0, "layers": list(layers),
+            "note": f"experiment.py:45-58 at scale: embed {d0} -> {list(layers)}, node dropout {c['node_dropout']} + message dropout "
+                    f"{list(c['mess_dropout'])} (device masks), batch {batch}, Adam lr {c['lr']}, BPR wd {c['wd']}, node_flag=True, train mode; "
+                    "step = forward + BPR + backward + Adam.step; the products timed are the full SpMMs of the step (3 forward L.E + the "
+                    "backward's L^T.dLE of the dense layers; the row-sparse last layer's backward product is a different kernel)"}
+
+
+def cpu_c3_train_sample(lap_cpu, model, ids, n_user, batch, n_threads):
+    """cpu_baseline of c3_train on a BOUNDED sample: ONE propagation layer (130 -> 128) of the same graph and initial weights on the
+    host - forward, BPR on the [E0 | norm(E1)] rows, backward, Adam - through the torch CPU oracle (eval-mode semantics: the
+    reference's CPU-drawn masks would add ~100 M generator draws); one run, no warm-up (about half a minute)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ngcf_oracle as orc
+    torch.set_num_threads(n_threads)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = ["user_embedding.weight", "item_embedding.weight", "w1_list.0.weight", "w1_list.0.bias", "w2_list.0.weight", "w2_list.0.bias"]
+    leaves = {k: sd[k].requires_grad_(True) for k in names}
+    opt = torch.optim.Adam(list(leaves.values()), lr=C3_TRAIN_CFG["lr"])
+    ids = {k: v.cpu() for k, v in ids.items()}
+    t0 = time.perf_counter()
+    all_E = orc.propagate_torch(lap_cpu, leaves[names[0]], leaves[names[1]], [leaves[names[2]]], [leaves[names[3]]], [leaves[names[4]]],
+                                [leaves[names[5]]])
+    u, p, ng = orc.gather_torch(all_E, n_user, ids["u_id"], ids["pos_item"], ids["neg_item"])
+    opt.zero_grad()
+    loss = orc.bpr_torch(u, p, ng, C3_TRAIN_CFG["wd"], batch)
+    loss.backward()
+    opt.step()
+    return time.perf_counter() - t0, float(loss.detach())
+
+
+def main_c3_train(args, pkg, lib, dev):
+    """--workload c3_train: the training step at scale as its own line."""
+    n_user, n_item, n_inter, d0, layers, seed = WORKLOADS["c3_train"]
+    coo = pkg.graphs.synthetic_bipartite(n_user, n_item, n_inter, seed=seed, device=dev, item_skew=not args.uniform_items)
+    lap = pkg.graphs.to_sparse_coo(coo)
+    r = c3_train_measure(pkg, lib, dev, lap, n_user, n_item, coo["nnz"], args.batch, args.steps, args.warmup, seed)
+    model, ids = r.pop("model"), r.pop("ids")
+    a = r["spmm_model_a_bytes"]
+    per_product = (a[str(d0)] + 2 * a[str(layers[0])]) / 3            # the forward's three products (130, 128, 128 wide); the backward's are 128 wide
+    achieved = per_product / (r["mean_spmm_product_ms"] * 1e-3) / 1e9
+    out = {
+        "metric": "NGCF 3-layer forward: propagated edges/sec + achieved HBM GB/s, d=128",
+        "value": r["value"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c3_train: the TRAINING step (experiment.py:45-58) on synthetic bipartite {n_user} users x {n_item} items, "
+                               f"{coo['interactions']} interactions, nnz(L)={coo['nnz']}; " + r["note"] +
+                               " - NOT the headline metric's forward-only step: edges/s here = n_layers * nnz(L) / step time",
+                   "n_user": n_user, "n_item": n_item, "interactions": coo["interactions"], "nnz_L": coo["nnz"], "d": d0,
+                   "n_layers": len(layers), "batch": args.batch, "parallelism": "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "spmm_swept_kernel (one SpMM product of the step, forward L.E or backward L^T.dLE)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": per_product, "launches_timed": r["spmm_products_timed"],
+                     "mean_launch_ms": r["mean_spmm_product_ms"],
+                     "note": "model A per product (SURVEY 8d); the matrix-core kernels of the backward (bwd_weight_kernel, "
+                             "layer_bwd_input_kernel) are priced in DESIGN.md 7 from profiles/r04_c3_train_kernel_stats.csv"},
+        "train": {k: v for k, v in r.items() if k not in ("value", "unit")},
+        "loss": r["loss"],
+    }
+    if not args.no_cpu_baseline:
+        dt, closs = cpu_c3_train_sample(lap.cpu(), model, ids, n_user, args.batch, host_cores())
+        out["cpu_baseline"] = {"value": coo["nnz"] / dt, "unit": "edges/s", "cores": host_cores(), "kind": "port", "cpu_model": cpu_model(),
+                               "seconds": dt, "loss": closs,
+                               "sample": f"ONE of the three layers ({d0} -> {layers[0]}) of the same graph and initial weights as a training step "
+                                         f"on the host: oracle/ngcf_oracle.py (torch CPU ops of NGCF.py:120-156 + bprloss.py) forward, "
+                                         f"torch autograd backward, torch.optim.Adam; no dropout; one run of {dt:.1f} s at {host_cores()} "
+                                         f"threads, torch {torch.__version__}; value = nnz(L) / that time"}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
 def edges_per_step_of(n_layer, nnz):
     return n_layer * nnz
 
@@ -368,15 +519,37 @@ def main():
     lib = _lib.load()
     t_start = time.perf_counter()
 
+    note_dir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"ngcf_bench_{os.environ.get('MASTER_PORT', '0')}")
+
     def note(msg):          # N > 1: a line per phase on stderr (every rank), so that a slow or failed phase can be found in the logs
         if world > 1:
-            print(f"[bench rank {rank} +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+            line = f"+{time.perf_counter() - t_start:.1f}s {msg}"
+            print(f"[bench rank {rank} {line}]", file=sys.stderr, flush=True)
+            try:            # ... and in a file per rank: the watchdog's line names every rank's last phase
+                os.makedirs(note_dir, exist_ok=True)
+                with open(os.path.join(note_dir, f"rank{rank}.note"), "w") as f:
+                    f.write(line)
+            except OSError:
+                pass
+
+    def last_notes():
+        out = {}
+        for q in range(world):
+            try:
+                out[str(q)] = open(os.path.join(note_dir, f"rank{q}.note")).read()
+            except OSError:
+                out[str(q)] = None
+        return out
     note("process group up")
 
     if args.workload == "c1_train":
         if world != 1:
             raise SystemExit("c1_train is a single-GPU configuration")
         return main_train(args, pkg, dev)
+    if args.workload == "c3_train":
+        if world != 1:
+            raise SystemExit("c3_train is a single-GPU configuration")
+        return main_c3_train(args, pkg, lib, dev)
     n_user, n_item, n_inter, d0, layers, seed = WORKLOADS[args.workload]
     seoul = args.workload in ("c1", "c2")
     full_forward = d0 % 5 == 0                                # a width the reference accepts: time the whole NGCF.forward
@@ -457,6 +630,7 @@ def main():
         torch.cuda.synchronize()
 
     import ctypes as C
+    host_issue = [None, None]
 
     def timed(step_fn, prof):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
@@ -466,11 +640,16 @@ def main():
         note("warm-up done")
         if prof:
             lib.ngcf_prof_enable(1)                           # hipEvent pair around every SpMM launch
+            if world > 1 and hasattr(sh, "p2p_stats"):
+                sh.p2p_stats(reset=True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             last = step_fn()
+        host_issue[0] = (time.perf_counter() - t0) / args.steps * 1e3      # what the host spent issuing (incl. its waits for peers)
         barrier()
         el = time.perf_counter() - t0
+        if prof and world > 1 and hasattr(sh, "p2p_stats"):
+            host_issue[1] = sh.p2p_stats()
         n_l, ms = C.c_int64(), C.c_double()
         if prof:
             _lib.check(lib.ngcf_prof_collect(C.byref(n_l), C.byref(ms)))
@@ -482,8 +661,19 @@ def main():
         assert torch.isfinite(last).item(), "non-finite loss"
         return el, last, n_l, ms
 
+    rccl_ranks = None
+    if world > 1 and dist.get_backend() == "nccl":
+        try:       # the size of the process group's own RCCL communicator, asked of the library (ngcf_comm_size, include/ngcf_hip.h)
+            import ctypes as _C
+            comm = dist.group.WORLD._get_backend(dev)._comm_ptr()
+            n_r = _C.c_int(0)
+            _lib.check(lib.ngcf_comm_size(_C.c_void_p(int(comm)), _C.byref(n_r)))
+            rccl_ranks = int(n_r.value)
+        except Exception as exc:  # noqa: BLE001
+            rccl_ranks = f"unavailable: {exc!r}"[:120]
     torch.set_grad_enabled(False)                             # the metric is the forward pass (inference path)
     dt, loss, n_launch, spmm_ms = timed(step, True)
+    headline_host = list(host_issue)
     note(f"headline timed: {dt / args.steps * 1e3:.3f} ms per step")
     n_layer = len(layers)
 
@@ -522,7 +712,10 @@ def main():
                        "hipgraph": bool(args.hipgraph),
                        "parallelism": "single GPU" if world == 1 else
                        f"row-partition x{world}, exchange={args.exchange} ({ngcf_dist.SCHEME_NOTES[args.exchange]}), transport={sh.backend}"
-                       + (f" (p2p fell back: {sh.p2p_error})" if getattr(sh, "p2p_error", None) else "")},
+                       + (f" (p2p fell back: {sh.p2p_error})" if getattr(sh, "p2p_error", None) else ""),
+                       **({} if world == 1 else {"exchange": args.exchange, "transport": sh.backend,
+                                                 "p2p_mode": getattr(getattr(sh, "p2p", None), "mode", None),
+                                                 "rccl_ranks": rccl_ranks, "process_group_backend": dist.get_backend()})},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch, "launches_timed": int(n_launch.value),
@@ -537,6 +730,14 @@ def main():
                             "note": "explanatory, not the headline: roofline.frac stays SURVEY 8d model A"},
             "loss": float(loss),
         }
+        out["host_issue_ms_per_step"] = headline_host[0]          # rank 0: wall time of the step loop before the closing barrier
+        if world > 1:
+            st = headline_host[1]                                 # rank 0: host time inside the exchange's waits (CU-free transport only)
+            out["p2p_host"] = None if not st else {**st, "host_blocked_ms_per_step": st["host_blocked_ms"] / args.steps,
+                                                   "note": "the exchange runs no kernel and moves rows on copy engines; its cost is host "
+                                                           "time in bounded waits for the peers' publications - zero when they are there"}
+            out["p2p_error"] = getattr(sh, "p2p_error", None)     # why the CU-free transport was not used (None: it was, or was not asked for)
+            out["secondary_overrun"] = False                      # True only on a line the watchdog printed
         return out
 
     # N > 1: what follows the headline (the RCCL cross-check, the other exchange scheme) must not be able to lose it: a
@@ -557,8 +758,11 @@ def main():
                     return
                 line_done[0] = True
                 if rank == 0:
+                    fallback["secondary_overrun"] = True
+                    fallback["last_phase_per_rank"] = last_notes()
                     print(json.dumps(fallback), flush=True)
-            os._exit(0)
+                    sys.stdout.flush()
+            os._exit(3)            # the line is out; a hang in a secondary is still a failure the harness must see
         watchdog = threading.Timer(budget + (0.0 if rank == 0 else 5.0), overrun)
         watchdog.daemon = True
         watchdog.start()
@@ -644,21 +848,20 @@ def main():
                 ids = {k: torch.randint(0, c, (args.batch,), generator=gs).to(dev)
                        for k, c in (("u_id", nu), ("pos_item", ni), ("neg_item", ni), ("age", 76), ("sex", 2), ("month", 13),
                                     ("day", 32), ("dow", 7))}
-                fwd_s = pkg.GraphedForward(ms, args.batch, 0)
-                fwd_s(year=torch.full((args.batch,), 18, device=dev), node_flag=False, **ids)
                 crit_s = pkg.BPR(0.025, args.batch)
-                for _ in range(20):
-                    ls = crit_s(*fwd_s.replay())
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(200):
-                    ls = crit_s(*fwd_s.replay())
-                torch.cuda.synchronize()
-                ms_step = (time.perf_counter() - t0) / 200 * 1e3
+                fwd_s = pkg.GraphedForward(ms, args.batch, 0, criterion=crit_s)     # forward + BPR: one graph launch per step
+                fwd_s(year=torch.full((args.batch,), 18, device=dev), node_flag=False, **ids)
+
+                def step_s():
+                    fwd_s.replay()
+                    return fwd_s.loss
+                med, lo, hi, per, ls = timed_blocks(step_s, blocks=5, steps=40, warmup=20)
                 secondary[f"{wl}_seoul_shaped_hipgraph"] = {
-                    "ms_per_step": ms_step, "value": len(lay_s) * coo_s["nnz"] / (ms_step * 1e-3), "unit": "edges/s", "loss": float(ls),
+                    "ms_per_step": med, "ms_per_step_min": lo, "ms_per_step_max": hi, "blocks_ms_per_step": [round(x, 4) for x in per],
+                    "value": len(lay_s) * coo_s["nnz"] / (med * 1e-3), "unit": "edges/s", "loss": float(ls),
                     "note": f"{nu} users x {ni} items, nnz(L)={coo_s['nnz']}, embed_size={e0}, layers={list(lay_s)}, batch={args.batch}: "
-                            "NGCF.forward (injection, propagation, gathers) replayed as a hipGraph + BPR, 200 steps after 20"}
+                            "NGCF.forward (injection, propagation, gathers) + BPR replayed as ONE hipGraph; five blocks of 40 steps after 20 "
+                            "(median / min / max; the garbage collector is off inside a block)"}
                 del fwd_s, ms
             except Exception as exc:  # noqa: BLE001
                 secondary[f"{wl}_seoul_shaped_hipgraph"] = {"error": repr(exc)[:300]}
@@ -671,10 +874,21 @@ def main():
                 secondary[f"c1_train_{mode}_masks"] = train_secondary(pkg, dev, args.batch, mode)
             except Exception as exc:  # noqa: BLE001
                 secondary[f"c1_train_{mode}_masks"] = {"error": repr(exc)[:300]}
+        try:       # the steady state of the reference's own loop: eval() at the end of epoch 1 is never undone (experiment.py:61,72)
+            secondary["c1_train_eval_mode_device_masks"] = train_secondary(pkg, dev, args.batch, "device", eval_mode=True)
+        except Exception as exc:  # noqa: BLE001
+            secondary["c1_train_eval_mode_device_masks"] = {"error": repr(exc)[:300]}
         try:
             secondary["c1_train_device_masks_hipgraph"] = train_secondary(pkg, dev, args.batch, "device", 100, 10, graphed=True)
         except Exception as exc:  # noqa: BLE001
             secondary["c1_train_device_masks_hipgraph"] = {"error": repr(exc)[:300]}
+        if args.workload == "c3":
+            try:   # the training step at scale on the headline's own graph (own line: --workload c3_train)
+                r3 = c3_train_measure(pkg, lib, dev, lap, n_user, n_item, nnz, args.batch, steps=5, warmup=2, seed=seed)
+                r3.pop("model"), r3.pop("ids")
+                secondary["c3_train_device_masks"] = r3
+            except Exception as exc:  # noqa: BLE001
+                secondary["c3_train_device_masks"] = {"error": repr(exc)[:300]}
         torch.set_grad_enabled(False)
 
     out = build_line(dt, loss, n_launch, spmm_ms, sh if world > 1 else None, spmm_shapes, local_nnz)

@@ -379,7 +379,15 @@ int ngcf_comm_size(void *nccl_comm, int *n_ranks);
  *   ngcf_p2p_ack / ngcf_p2p_wait_acks   the reverse notice: a producer overwrites a region only after all peers have read it
  *   ngcf_p2p_fence    later copies start only after what `stream` holds now (the last readers of their destinations)
  *   ngcf_p2p_join     `stream` waits (stream dependency, no kernel) for every copy enqueued since the last join
+ *   ngcf_p2p_stats    host time spent inside those waits so far, number of waits, number that found their word missing
  * `seq` must grow from call to call per slot (64 slots).  A wait that exceeds timeout_ms fails with NGCF_ERR_HIP.
+ * Why the waiting is done by host threads and the publishing by a non-blocking host function (r04, tools/memops_lab.hip,
+ * profiles/r04_memops_lab.txt): on this runtime hipStreamWriteValue64 / hipStreamWaitValue64 on host-registered memory, 8-byte
+ * copies and event-less flag kernels are all SHADER work - beside a kernel that holds every CU (the L2-swept SpMM) none of them
+ * starts before it ends (2.6 ms late beside a 2.65 ms kernel; a host function: 24 us), and a pending wait-value occupies a CU
+ * (a one-workgroup-per-CU kernel launched behind it takes twice as long); a BLOCKING host function on a copy stream would take
+ * the host out of the path, but the runtime runs every stream's host functions on one thread: a blocked one holds the
+ * publishing ones of the same process (released only by its time-out).
  * ngcf_sum_slots_f32: out = slots[0] + slots[1] + ... (fixed order): the owner's side of a reduce-scatter done with pulls.
  */
 typedef struct ngcf_p2p ngcf_p2p_t;
@@ -395,6 +403,7 @@ int ngcf_p2p_ack(ngcf_p2p_t *p2p, int peer, int slot, uint64_t seq);
 int ngcf_p2p_wait_acks(ngcf_p2p_t *p2p, int slot, uint64_t seq, double timeout_ms);
 int ngcf_p2p_fence(ngcf_p2p_t *p2p, void *stream);
 int ngcf_p2p_join(ngcf_p2p_t *p2p, void *stream);
+int ngcf_p2p_stats(ngcf_p2p_t *p2p, double *blocked_ms, int64_t *waits, int64_t *waits_blocked, int reset);
 int ngcf_sum_slots_f32(const float *slots, int64_t slot_stride, int n_slots, int64_t n, float *out, void *stream);
 
 #ifdef __cplusplus

@@ -50,6 +50,32 @@ def _write_e0(owner, user_w, item_w, all_E, U, d0):
     return all_E[:, :d0]
 
 
+def _ref_counts(t):
+    return sys.getrefcount(t), torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class _Probe:
+    pass
+
+
+def _calibrate():
+    """What `_ref_counts(owner.attr)` reads for a tensor that only `owner.attr` references (interpreter-specific constants)."""
+    o = _Probe()
+    o.t = torch.empty(1)
+    return _ref_counts(o.t)
+
+
+_FREE_COUNTS = _calibrate()
+
+
+def held_elsewhere(t: torch.Tensor) -> bool:
+    """Call as `held_elsewhere(owner.attr)`: True when anything besides that one attribute references the tensor object, or any
+    other tensor (a view, a detached alias) shares its storage.  A retained result buffer is overwritten only when this is False:
+    a caller who kept the previous result keeps it intact, as with a fresh allocation per call.  (Same call depth as the
+    calibration above: the counts include this function's own parameter.)"""
+    return (sys.getrefcount(t), torch._C._storage_Use_Count(t.untyped_storage()._cdata)) != _FREE_COUNTS
+
+
 class E0Cache:
     """The all_E of the previous inference forward, kept so that block 0 - E0 = cat(user table, item table), NGCF.py:120 - need not
     be copied again while the tables are unchanged (r04; SURVEY 2.2 K4: 563 MB through `copy_rows_kernel` per forward at C3, 0.21 ms).
@@ -88,22 +114,40 @@ class E0Cache:
         return (user_w.data_ptr(), int(user_w._version), tuple(user_w.shape), item_w.data_ptr(), int(item_w._version),
                 tuple(item_w.shape), tuple(widths), str(dev))
 
+    def _counts(self, owner):
+        """(Python references to all_E, to each of the module's two views, tensors on the storage) - read the same way here and in
+        the calibration below, so the constants of this interpreter / torch build cancel out."""
+        d = owner.__dict__
+        return (sys.getrefcount(self.all_E), sys.getrefcount(d["all_users_emb"]), sys.getrefcount(d["all_items_emb"]),
+                torch._C._storage_Use_Count(self.all_E.untyped_storage()._cdata))
+
+    _free = {}
+
+    @classmethod
+    def _free_counts(cls, padded: bool):
+        """What `_counts` reads when nobody but the module and its cache holds the forward's tensors: measured once per layout of
+        all_E (`_alloc_all_E`: a plain [N, D] tensor, or - D not a multiple of 4 - a [N, D] view of a padded buffer) on a toy built
+        the way `NGCF.propagate` builds the real thing."""
+        if padded not in cls._free:
+            o, c = _Probe(), cls()
+            t = torch.empty((4, 8))[:, :6] if padded else torch.empty((4, 8))
+            o._all_E, o.all_users_emb, o.all_items_emb = t, t[:2, :], t[2:, :]
+            c.all_E = t
+            del t
+            cls._free[padded] = c._counts(o)
+        return cls._free[padded]
+
     def only_the_modules(self, owner) -> bool:
         """True iff the cached all_E and the module's two views of it are referenced by the module (and this cache) alone."""
         d = owner.__dict__
-        if d.get("_all_E") is not self.all_E or self.all_E is None:
+        if self.all_E is None or d.get("_all_E") is not self.all_E:
             return False
-        # references to the tensor object: this cache, owner._all_E, getrefcount's own argument, and the one the C++ side keeps
-        # on the Python object of a tensor that has views (measured, torch 2.10; a count that differs only ever costs the copy)
-        if sys.getrefcount(self.all_E) != 4:
-            return False
+        root = self.all_E._base if self.all_E._base is not None else self.all_E
         for name in ("all_users_emb", "all_items_emb"):
-            if d.get(name) is None or d[name]._base is not self.all_E:
+            if d.get(name) is None or d[name]._base is not root:
                 return False
-            if sys.getrefcount(d[name]) != 2:                      # the module's dict + getrefcount's argument
-                return False
-        # tensors sharing the storage: all_E, the two views (each holds all_E as its `_base` - counted above), the temporary wrapper
-        return torch._C._storage_Use_Count(self.all_E.untyped_storage()._cdata) == 4
+        del root
+        return self._counts(owner) == self._free_counts(self.all_E._base is not None)
 
 
 def _all_E_with_e0(owner, user_w, item_w, N, widths, dev):

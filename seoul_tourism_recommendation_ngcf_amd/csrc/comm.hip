@@ -137,6 +137,8 @@ struct ngcf_p2p {
     hipStream_t pub_stream = nullptr;    // carries the host functions of publish()
     P2pStore payload[kP2pPayloads];
     int next_payload = 0;
+    double blocked_ms = 0;               // how long this rank's HOST thread has sat in p2p_wait_word so far (ngcf_p2p_stats)
+    int64_t waits = 0, waits_blocked = 0;
     uint64_t *pub(int r, int slot) { return shm + (size_t)r * kP2pSlots + slot; }
     uint64_t *ack(int reader, int owner, int slot) { return shm + (size_t)world * kP2pSlots + ((size_t)reader * world + owner) * kP2pSlots + slot; }
     P2pStore *store(uint64_t *dst, uint64_t val)
@@ -260,11 +262,17 @@ extern "C" int ngcf_p2p_publish(ngcf_p2p_t *p, int slot, uint64_t seq, void *str
     return NGCF_OK;
 }
 
-static int p2p_wait_word(const uint64_t *w, uint64_t seq, double timeout_ms, const char *what, int who, int slot)
+static int p2p_wait_word(ngcf_p2p *p, const uint64_t *w, uint64_t seq, double timeout_ms, const char *what, int who, int slot)
 {
+    ++p->waits;
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) >= seq) return NGCF_OK;     // the usual case: the hosts run ahead of their GPUs
+    ++p->waits_blocked;
     const double t0 = now_ms();
     for (int spins = 0;; ++spins) {
-        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) >= seq) return NGCF_OK;
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) >= seq) {
+            p->blocked_ms += now_ms() - t0;
+            return NGCF_OK;
+        }
         if (spins > 2000) sched_yield();
         if ((spins & 1023) == 1023 && now_ms() - t0 > timeout_ms)
             return fail(NGCF_ERR_HIP, "p2p: timed out after %.0f ms waiting for %s of rank %d (slot %d, step %llu, seen %llu)", timeout_ms, what,
@@ -278,7 +286,7 @@ extern "C" int ngcf_p2p_pull(ngcf_p2p_t *p, int peer, int slot, uint64_t seq, in
     if (!p || peer < 0 || peer >= p->world || slot < 0 || slot >= kP2pSlots || !dst || bytes < 0 || src_off < 0 || src_off + bytes > p->bytes)
         return fail(NGCF_ERR_ARG, "p2p_pull: bad argument");
     if (!p->peer[(size_t)peer]) return fail(NGCF_ERR_ARG, "p2p_pull: rank %d is not connected", peer);
-    const int rc = p2p_wait_word(p->pub(peer, slot), seq, timeout_ms, "the data", peer, slot);
+    const int rc = p2p_wait_word(p, p->pub(peer, slot), seq, timeout_ms, "the data", peer, slot);
     if (rc != NGCF_OK) return rc;
     if (bytes == 0) return NGCF_OK;
     HIP_TRY(hipMemcpyAsync(dst, p->peer[(size_t)peer] + src_off, (size_t)bytes, hipMemcpyDeviceToDevice, p->copy[(size_t)peer]));
@@ -301,8 +309,23 @@ extern "C" int ngcf_p2p_wait_acks(ngcf_p2p_t *p, int slot, uint64_t seq, double 
     if (seq == 0) return NGCF_OK;
     for (int q = 0; q < p->world; ++q) {
         if (q == p->rank) continue;
-        const int rc = p2p_wait_word(p->ack(q, p->rank, slot), seq, timeout_ms, "the acknowledgement", q, slot);
+        const int rc = p2p_wait_word(p, p->ack(q, p->rank, slot), seq, timeout_ms, "the acknowledgement", q, slot);
         if (rc != NGCF_OK) return rc;
+    }
+    return NGCF_OK;
+}
+
+// how long the host thread has been held in waits so far (the exchange puts no kernel on a CU and the data moves on copy engines;
+// what it costs is host time in these waits: zero when the peers' publications are already there)
+extern "C" int ngcf_p2p_stats(ngcf_p2p_t *p, double *blocked_ms, int64_t *waits, int64_t *waits_blocked, int reset)
+{
+    if (!p) return fail(NGCF_ERR_ARG, "p2p_stats: null argument");
+    if (blocked_ms) *blocked_ms = p->blocked_ms;
+    if (waits) *waits = p->waits;
+    if (waits_blocked) *waits_blocked = p->waits_blocked;
+    if (reset) {
+        p->blocked_ms = 0;
+        p->waits = p->waits_blocked = 0;
     }
     return NGCF_OK;
 }

@@ -43,6 +43,7 @@ import torch.distributed as dist
 
 from . import _lib
 from . import engine as _eng
+from .autograd import held_elsewhere
 
 SCHEME_NOTES = {
     "allgather": "row partition (users and items, cut by stored entries) + RCCL all-gather of the carry per layer, user slab "
@@ -346,25 +347,48 @@ class DenseLayerFn(torch.autograd.Function):
 
 
 class _SumGrads(torch.autograd.Function):
-    """Identity on the (replicated) parameters; its backward adds every parameter's gradient over the ranks - the one all-reduce
-    per parameter and step of data-parallel training (each rank contributes the rows it owns)."""
+    """Identity on the (replicated) parameters; its backward makes every parameter's gradient complete on every rank - once per
+    parameter and step, as in data-parallel training.
+
+    `slabs` = {position in `params`: row bounds per rank}: that parameter (the user table) is read by rank r through rows
+    [bounds[r], bounds[r+1]) only, so its gradient is non-zero in that slab only and the slabs are disjoint: an ALL-GATHER of the
+    slabs (padded to the largest) gives every rank the full gradient - (W-1)/W x |table| received per rank instead of the
+    2 (W-1)/W x |table| of a ring all-reduce of W dense [U, d0] matrices that are zero outside one slab each (r04; at C3 / W = 8:
+    448 MB instead of 896 MB per rank and step for the 512 MB user table).  Everything else (the item table - every rank's user rows
+    gather from all items -, the weights) is summed by an all-reduce."""
 
     @staticmethod
-    def forward(ctx, group, *params):
-        ctx.group = group
+    def forward(ctx, group, slabs, *params):
+        ctx.group, ctx.slabs = group, dict(slabs or {})
         return tuple(p.view_as(p) for p in params)
 
     @staticmethod
     def backward(ctx, *grads):
         out = []
-        for gr in grads:
+        W = dist.get_world_size(ctx.group)
+        r = dist.get_rank(ctx.group)
+        for i, gr in enumerate(grads):
             if gr is None:
                 out.append(None)
                 continue
             gr = gr.contiguous()
-            dist.all_reduce(gr, group=ctx.group)
-            out.append(gr)
-        return (None, *out)
+            bounds = ctx.slabs.get(i)
+            if bounds is None or W == 1:
+                dist.all_reduce(gr, group=ctx.group)
+                out.append(gr)
+                continue
+            mx = max(max(bounds[q + 1] - bounds[q] for q in range(W)), 1)
+            send = gr.new_zeros((mx,) + tuple(gr.shape[1:]))
+            send[:bounds[r + 1] - bounds[r]] = gr[bounds[r]:bounds[r + 1]]
+            full = gr.new_empty((W * mx,) + tuple(gr.shape[1:]))
+            dist.all_gather_into_tensor(full, send, group=ctx.group)
+            res = torch.zeros_like(gr)                             # (rows no rank reads keep a zero gradient)
+            for q in range(W):
+                n_q = bounds[q + 1] - bounds[q]
+                if n_q:
+                    res[bounds[q]:bounds[q + 1]] = full[q * mx:q * mx + n_q]
+            out.append(res)
+        return (None, None, *out)
 
 
 class _DevMem:
@@ -446,6 +470,12 @@ class P2PExchange:
 
     def join(self):
         _lib.check(_lib.load().ngcf_p2p_join(self._h, _eng._stream()))
+
+    def stats(self, reset: bool = False):
+        """(host milliseconds spent blocked in waits, waits, waits that found their word missing) since creation / the last reset."""
+        ms, n, nb = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().ngcf_p2p_stats(self._h, C.byref(ms), C.byref(n), C.byref(nb), 1 if reset else 0))
+        return float(ms.value), int(n.value), int(nb.value)
 
     def peers_from(self, start: int):
         """All ranks, beginning after `start` (every rank starts its pulls at another peer: the links are used evenly)."""
@@ -798,7 +828,7 @@ class ShardedPropagation:
         # parameters enter through one Function whose backward all-reduces their gradients (once per step)
         params = [m.user_embedding.weight, m.item_embedding.weight] + [l.weight for l in m.w1_list] + [l.bias for l in m.w1_list] + \
                  [l.weight for l in m.w2_list] + [l.bias for l in m.w2_list]
-        outs = _SumGrads.apply(g, *params)
+        outs = _SumGrads.apply(g, {0: list(self.ub)}, *params)     # the user table is read through the rank's own slab only
         uw, iw = outs[0], outs[1]
         w1, b1 = outs[2:2 + n_layer], outs[2 + n_layer:2 + 2 * n_layer]
         w2, b2 = outs[2 + 2 * n_layer:2 + 3 * n_layer], outs[2 + 3 * n_layer:]
@@ -839,12 +869,24 @@ class ShardedPropagation:
         r, W, mi, PI = self.rank, self.world, self.mi, self.PI
         lo, nu, ni = self.ub[r], self.nu, self.ni
         ld = lambda d: (d + 31) // 32 * 32                         # noqa: E731
-        allE_u = torch.empty((nu, D), dtype=torch.float32, device=self.dev)       # this rank's users
-        allE_i = torch.empty((ni, D), dtype=torch.float32, device=self.dev)       # the items this rank owns
         d0 = widths[0]
         iw = m.item_embedding.weight.detach()
-        _eng.copy_rows(m.user_embedding.weight.detach()[lo:lo + nu], allE_u[:, :d0])
-        _eng.copy_rows(iw[self.ib[r]:self.ib[r + 1]], allE_i[:, :d0])
+        uwp, iwp = m.user_embedding.weight, m.item_embedding.weight
+        # r04: the result buffers of the previous pass are written again - and their block 0 (E0, NGCF.py:120) NOT copied again -
+        # while both tables are the same tensors at the same version and nobody else holds the previous result (held_elsewhere:
+        # a caller who kept it gets a fresh pair, as before).  At W = 8 that is the rank's share of the 0.21 ms E0 copy per pass.
+        e0_tag = (uwp.data_ptr(), int(uwp._version), iwp.data_ptr(), int(iwp._version), tuple(widths), nu, ni)
+        keep = (getattr(self, "_allE_tag", None) == e0_tag and getattr(self, "allE_u", None) is not None
+                and not self.allE_u.requires_grad and not held_elsewhere(self.allE_u) and not held_elsewhere(self.allE_i))
+        if keep:
+            allE_u, allE_i = self.allE_u, self.allE_i
+        else:
+            self.allE_u = self.allE_i = None
+            allE_u = torch.empty((nu, D), dtype=torch.float32, device=self.dev)   # this rank's users
+            allE_i = torch.empty((ni, D), dtype=torch.float32, device=self.dev)   # the items this rank owns
+            _eng.copy_rows(uwp.detach()[lo:lo + nu], allE_u[:, :d0])
+            _eng.copy_rows(iw[self.ib[r]:self.ib[r + 1]], allE_i[:, :d0])
+            self._allE_tag = e0_tag
         # layer-0 item replica from the replicated parameter table (padded numbering): local copies, no communication - and none at
         # all while the table is the same tensor at the same version as in the previous pass (inference loops)
         ei = self._buf(("ei", 0), (PI, ld(d0)))[:, :d0]
@@ -858,7 +900,8 @@ class ShardedPropagation:
         eu = allE_u[:, :d0]
         if d0 % 4 or D % 4:                                        # rows of all_E are not 16-byte aligned: an aligned copy to gather from
             eu = self._buf(("eu0",), (nu, ld(d0)))[:, :d0]
-            _eng.copy_rows(m.user_embedding.weight.detach()[lo:lo + nu], eu)
+            if not keep:
+                _eng.copy_rows(uwp.detach()[lo:lo + nu], eu)
         ex = self.p2p if self.backend == "p2p" else None
         self._calls += 1
         base = self._calls * (n_layer + 1)
@@ -1065,11 +1108,95 @@ class ShardedPropagation:
         return allE_u, allE_i
 
     # -- gathers + BPR (NGCF.py:151-156, bprloss.py:15-22) ---------------------------------------
-    def _gather_inference(self, u_id, pos_item, neg_item):
-        """The three row gathers with ONE exchange: every rank copies the rows it owns into a zero-filled [Bu + Bp + Bn, D] buffer
-        (ngcf_gather_rows_f32 skips ids outside the rank's range: the status word of that call is a throw-away) and one all-reduce
-        adds the buffers - x + 0 is exact, so every rank ends up with the owners' bits."""
+    def p2p_stats(self, reset: bool = False):
+        """Host time this rank spent blocked inside the exchanges' waits (propagation + gathers), as a dict; None without p2p."""
+        exs = [e for e in (getattr(self, "p2p", None), getattr(self, "_gx", None)) if e is not None]
+        if not exs:
+            return None
+        got = [e.stats(reset) for e in exs]
+        return {"host_blocked_ms": sum(g[0] for g in got), "waits": sum(g[1] for g in got), "waits_blocked": sum(g[2] for g in got)}
+
+    def invalidate_e0(self):
+        """Forget that block 0 of the retained result buffers and the layer-0 item replica hold the current tables: the next pass
+        copies them again.  Needed only after a write to an embedding table through `.data` (invisible to the version counters)."""
+        self._allE_tag = self._ei0_tag = None
+
+    def _owned_rows(self, out, sets):
+        """The rows of the batch this rank owns, gathered into their positions of `out` [sum of sizes, D]; positions other ranks own
+        are left alone (ngcf_gather_rows_f32 skips ids outside the range: the status word of that call is a throw-away)."""
         lib = _lib.load()
+        D = int(out.shape[1])
+        scrap = self._buf(("scrap_status",), (1,)).view(torch.int32)
+        at = 0
+        with _eng._on(self.dev):
+            for table, ix, lo, n_rows in sets:
+                b = int(ix.numel())
+                if n_rows and b:
+                    loc = (ix.to(torch.int64) - lo).contiguous()
+                    _lib.check(lib.ngcf_gather_rows_f32(_eng._ptr(table), _eng._row_major_ld(table, "table"), D, _eng._ptr(loc), b, 0, n_rows,
+                                                        _eng._ptr(out[at:at + b]), D, _eng._ptr(scrap), _eng._stream()))
+                at += b
+
+    def _owner_index(self, u_id, pos_item, neg_item, Btot):
+        """int64[Btot]: position b of the batch is row owner(b) * Btot + b of the [W * Btot, D] block of pulled rows.  Computed once
+        per set of index tensors (same objects at the same version: a loop over fixed batches pays nothing)."""
+        ids = (u_id, pos_item) + ((neg_item,) if neg_item is not None else ())
+        key = tuple((id(t), int(t._version), int(t.numel())) for t in ids)
+        hit = getattr(self, "_owner_idx", None)
+        if hit is not None and hit[0] == key and all(a() is b for a, b in zip(hit[2], ids)):
+            return hit[1]
+        import weakref
+        dev = self.dev
+        if self.mode == "bipartite":
+            ub, ib = torch.tensor(self.ub, device=dev), torch.tensor(self.ib, device=dev)
+        else:
+            ub, ib = torch.tensor(self.layout.ub, device=dev), torch.tensor(self.layout.ib, device=dev) - self.U
+        W = self.world
+        own = [(torch.searchsorted(ub, u_id, right=True) - 1).clamp(0, W - 1)]
+        own += [(torch.searchsorted(ib, t, right=True) - 1).clamp(0, W - 1) for t in ids[1:]]
+        idx = (torch.cat(own) * Btot + torch.arange(Btot, device=dev)).contiguous()
+        self._owner_idx = (key, idx, [weakref.ref(t) for t in ids])
+        return idx
+
+    def _gather_p2p(self, sets, sizes, D, u_id, pos_item, neg_item):
+        """The three row gathers over the CU-free exchange (r04; r03 used an all-reduce of a zero-filled [B, D] buffer - an RCCL
+        kernel on the CUs at the end of every pass): every rank gathers the rows it OWNS into its exchange buffer and publishes;
+        every rank pulls every peer's block (copy engines; W blocks of sum(sizes) x D floats = 6.3 MB each at C3's batch, all links
+        at once) and one gather kernel picks position b out of its owner's block.  Bit-exact copies of the owners' rows.  Two
+        regions in turn, so that a rank overwrites a block only after every peer has read it (acknowledgements per pass)."""
+        Btot = sum(sizes)
+        need = Btot * D
+        gx = getattr(self, "_gx", None)
+        if gx is None or self._gx_region < need:                   # (collective: every rank sees the same sizes in the same call)
+            if gx is not None:
+                for reg_ in (0, 1):                                # every peer has finished reading the old buffer before it goes
+                    last = self._gx_calls - ((self._gx_calls - 1 - reg_) % 2)
+                    gx.wait_acks(reg_, max(last, 0))
+                gx.close()
+            self._gx_region = need
+            self._gx = gx = P2PExchange(self.group, self.dev, 2 * need)
+            self._gx_calls = 0
+        reg = self._gx_calls % 2
+        self._gx_calls += 1
+        seq = self._gx_calls
+        gx.wait_acks(reg, max(seq - 2, 0))                              # the previous contents of this region have been read by everyone
+        mine = gx.floats(reg * self._gx_region, need).view(Btot, D)
+        self._owned_rows(mine, sets)
+        gx.publish(reg, seq)
+        slots = self._buf(("gather_slots",), (self.world, Btot, D))
+        gx.fence()                                                 # the pulls land after the previous pass's reader of `slots`
+        for q in gx.peers_from(self.rank):
+            gx.pull(q, reg, seq, reg * self._gx_region, slots[q])
+            gx.ack(q, reg, seq)
+        gx.join()
+        idx = self._owner_index(u_id, pos_item, neg_item, Btot)
+        out = _eng.gather_rows(slots.view(self.world * Btot, D), idx, self.status)
+        return torch.split(out, sizes)
+
+    def _gather_inference(self, u_id, pos_item, neg_item):
+        """The three row gathers with ONE exchange.  p2p transport: `_gather_p2p`.  torch.distributed: every rank copies the rows it
+        owns into a zero-filled [Bu + Bp + Bn, D] buffer and one all-reduce adds the buffers - x + 0 is exact, so every rank ends
+        up with the owners' bits."""
         r = self.rank
         if self.mode == "bipartite":
             u_lo, u_n, i_lo, i_n = self.ub[r], self.nu, self.ib[r], self.ni
@@ -1080,18 +1207,13 @@ class ShardedPropagation:
             sets.append((self.allE_i, neg_item, i_lo, i_n))
         D = int(self.allE_u.shape[1])
         sizes = [int(ix.numel()) for _, ix, _, _ in sets]
-        buf = torch.zeros((sum(sizes), D), dtype=torch.float32, device=self.dev)
-        scrap = self._buf(("scrap_status",), (1,)).view(torch.int32)
-        at = 0
-        with _eng._on(self.dev):
-            for (table, ix, lo, n_rows), b in zip(sets, sizes):
-                if n_rows and b:
-                    loc = (ix.to(torch.int64) - lo).contiguous()
-                    _lib.check(lib.ngcf_gather_rows_f32(_eng._ptr(table), _eng._row_major_ld(table, "table"), D, _eng._ptr(loc), b, 0, n_rows,
-                                                        _eng._ptr(buf[at:at + b]), D, _eng._ptr(scrap), _eng._stream()))
-                at += b
-        dist.all_reduce(buf, group=self.group)
-        outs = torch.split(buf, sizes)
+        if self.backend == "p2p" and sum(sizes) > 0 and os.environ.get("NGCF_DIST_GATHER", "p2p") == "p2p":
+            outs = self._gather_p2p(sets, sizes, D, u_id, pos_item, neg_item)
+        else:
+            buf = torch.zeros((sum(sizes), D), dtype=torch.float32, device=self.dev)
+            self._owned_rows(buf, sets)
+            dist.all_reduce(buf, group=self.group)
+            outs = torch.split(buf, sizes)
         return outs[0], outs[1], (outs[2] if neg_item is not None else torch.empty(0))
 
     def gather(self, u_id: torch.Tensor, pos_item: torch.Tensor, neg_item: torch.Tensor):

@@ -31,10 +31,11 @@ class _Buffers:
 
 class GraphedForward:
     def __init__(self, model, batch_size: int, year_idx: int = 0, with_neg: bool = True, pos_size: int = None,
-                 neg_size: int = None):
+                 neg_size: int = None, criterion=None):
         """`batch_size`: length of u_id and of the five feature index vectors; `pos_size` / `neg_size`: lengths of pos_item /
         neg_item when they differ from it (experiment.py:82-91 passes 25 users and 25 candidate items; demo.py one user row per
-        query and every item)."""
+        query and every item).  `criterion` (a `BPR` module, r04): the loss of the gathered rows is captured too - the whole step
+        forward + BPR (experiment.py:45-56 without the backward) is then ONE graph launch; `self.loss` holds it after a replay."""
         if model.training:
             raise RuntimeError("GraphedForward captures the eval-mode forward: call model.eval() first")
         if model.emb_size % 5 != 0:
@@ -50,6 +51,9 @@ class GraphedForward:
         self.inputs["neg_item"] = z(max(self.Bn, 1))
         self.csr = model.laplacian_csr(self.year_idx)      # built (and planned) outside the capture; kept alive here
         self.bufs = _Buffers()
+        if criterion is not None and not self.with_neg:
+            raise RuntimeError("GraphedForward: capturing the loss needs the negative items (with_neg=True)")
+        self.criterion, self._loss_ws, self.loss = criterion, _eng.Workspace(), None
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = torch.full((model.n_user,), -1, dtype=torch.int32, device=dev)
         # the weights the injection overwrites must look the same at capture time as before it
@@ -58,12 +62,17 @@ class GraphedForward:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                      # warm-up: every cached buffer exists before the capture
             for _ in range(2):
-                self._body()
+                out = self._body()
+                if criterion is not None:
+                    self._loss(out)
+            del out
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._body()
+            if criterion is not None:
+                self.loss = self._loss(self.out)
         torch.cuda.synchronize(dev)
         model.user_embedding.weight.data[:1].copy_(saved)  # row 0 was injected with the all-zero warm-up batch
         self.status.zero_()
@@ -85,6 +94,11 @@ class GraphedForward:
             if n is None:
                 n = torch.empty(0)
         return all_E, u, p, n
+
+    def _loss(self, out):
+        """bprloss.py:15-22 on the gathered rows, with a workspace of this object's own (the graph bakes its address in)."""
+        c = self.criterion
+        return _eng.bpr_loss(out[1], out[2], out[3], c.weight_decay, c.batch_size, self._loss_ws)
 
     def __call__(self, u_id, age, sex, month, day, dow, pos_item, neg_item=None, year=None, node_flag=False, check=True):
         """Same arguments as `NGCF.forward` (keyword calls work); `year` is not inspected - the slice was fixed at
@@ -115,7 +129,7 @@ class GraphedForward:
     def _baked_pointers(self):
         b = self.bufs
         return tuple(t.data_ptr() for t in (b._ws.buf, b._carry[0], b._carry[1], self.scratch,
-                                            self.status) if t is not None)
+                                            self.status, self._loss_ws.buf) if t is not None)
 
     def replay(self, check: bool = True):
         """Replay on whatever `self.inputs[...]` (the graph's static int64 index buffers) hold: callers that write their

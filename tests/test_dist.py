@@ -219,7 +219,7 @@ def _cpu_train_worker(rank, world, port, ret):
         Lu = torch.sparse_coo_tensor(torch.stack([sur - lo, ppos]), suv, (hi - lo, PI))
         Lit = torch.sparse_coo_tensor(torch.stack([ppos, sur - lo]), suv, (PI, hi - lo))
         mine = leaves()
-        outs = nd._SumGrads.apply(None, *mine)
+        outs = nd._SumGrads.apply(None, {0: eb}, *mine)       # the user table's gradient travels as an all-gather of the ranks' slabs
         uw, iw = outs[0], outs[1]
         pw1, pb1, pw2, pb2 = outs[2:2 + n], outs[2 + n:2 + 2 * n], outs[2 + 2 * n:2 + 3 * n], outs[2 + 3 * n:]
         src = torch.zeros(PI, dtype=torch.int64)
@@ -358,6 +358,37 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False, collec
         loss = pkg.BPR(0.025, 64)(u, p, n)
         ref = orc.bpr_torch(want[:U][u_id].cpu(), want[U:][pos].cpu(), want[U:][neg].cpu(), 0.025, 64)
         ok = ok and abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+        # the gathers are bit-exact copies of the OWNERS' rows (r04: over p2p every rank pulls every owner's block and picks): the
+        # rows this rank owns can be checked against its own slab, and every later gather (the two exchange regions in turn) agrees
+        if mode == "bipartite":
+            lo_u, hi_u, lo_i, hi_i = sh.ub[rank], sh.ub[rank + 1], sh.ib[rank], sh.ib[rank + 1]
+        else:
+            lo_u, hi_u, lo_i, hi_i = sh.layout.ub[rank], sh.layout.ub[rank + 1], sh.layout.ib[rank] - U, sh.layout.ib[rank + 1] - U
+        mu, mp_, mn = (u_id >= lo_u) & (u_id < hi_u), (pos >= lo_i) & (pos < hi_i), (neg >= lo_i) & (neg < hi_i)
+        ok = ok and torch.equal(u[mu], au[u_id[mu] - lo_u]) and torch.equal(p[mp_], ai[pos[mp_] - lo_i]) and torch.equal(n[mn], ai[neg[mn] - lo_i])
+        for it in range(3):
+            time.sleep(0.01 * ((rank + it) % 2))
+            u2, p2, n2 = sh.gather(u_id, pos, neg)
+            ok = ok and torch.equal(u2, u) and torch.equal(p2, p) and torch.equal(n2, n)
+        u3, p3, _ = sh.gather(u_id[:7], pos[:9], torch.empty(0))   # another shape, no negatives (experiment.py:82-91)
+        ok = ok and torch.equal(u3, u[:7]) and torch.equal(p3, p[:9])
+        if mode == "bipartite":
+            # r04: nobody holds the previous result -> the same buffers are written again and E0 is not copied again; an in-place
+            # update of a table (an optimizer step) is seen through its version counter
+            del au, ai, u2, p2, n2, u3, p3
+            with torch.no_grad():
+                sh.propagate()
+                ptr = sh.allE_u.data_ptr()
+                sh.propagate()
+                ok = ok and sh.allE_u.data_ptr() == ptr and torch.equal(sh.allE_u, first[0]) and torch.equal(sh.allE_i, first[1])
+                model.user_embedding.weight.add_(0.25)
+                model.item_embedding.weight.mul_(0.5)
+                a1 = sh.propagate()
+                a1 = (a1[0].clone(), a1[1].clone())
+                sh.invalidate_e0()
+                a2 = sh.propagate()
+                ok = ok and torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1]) and not torch.equal(a1[0], first[0])
+                ok = ok and torch.equal(a2[0][:, :128], model.user_embedding.weight[lo_u:hi_u])
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

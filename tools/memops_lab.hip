@@ -83,6 +83,26 @@ static void store_cb(void *a)
     __atomic_store_n(s->dst, s->val, __ATOMIC_RELEASE);
 }
 
+struct Block {
+    volatile uint64_t *w;
+    uint64_t want;
+    double waited_us;
+    int timed_out;
+};
+// a host function that BLOCKS its stream until *w >= want (bounded: 2 s) - "hipStreamWaitValue on the host"
+static void block_cb(void *a)
+{
+    Block *b = (Block *)a;
+    const double t0 = now_us();
+    b->timed_out = 0;
+    while (__atomic_load_n(b->w, __ATOMIC_ACQUIRE) < b->want)
+        if (now_us() - t0 > 2e6) {
+            b->timed_out = 1;
+            break;
+        }
+    b->waited_us = now_us() - t0;
+}
+
 // host waits (bounded) until *w >= v; returns elapsed us or -1
 static double host_wait(volatile uint64_t *w, uint64_t v, double t0, double timeout_us = 2e6)
 {
@@ -281,6 +301,60 @@ int main(int argc, char **argv)
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("E 1 ms hog launched behind a pending %s: finished before the release %d, took %.3f ms (1.0 = every CU at once, 2.0 = one CU was taken)\n",
                mode == 0 ? "wait-value" : "spin kernel", (int)done, ms);
+    }
+    // ---- F: a BLOCKING host function on a copy stream as the wait (the main thread never blocks).  Do the callbacks of different
+    // streams run on different threads - i.e. can a store callback on one stream release a blocked callback on another?
+    {
+        hipStream_t st[8];
+        for (int i = 0; i < 8; ++i) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        static Block blk[8];
+        static Store rel;
+        for (int n_blocked : {1, 7}) {
+            w[12] = 0;
+            for (int i = 0; i < n_blocked; ++i) {
+                blk[i].w = w + 12;
+                blk[i].want = 1;
+                CK(hipLaunchHostFunc(st[i], block_cb, &blk[i]));
+                CK(hipMemcpyAsync(dshm + 40 + i, dvals + i, 8, hipMemcpyDeviceToHost, st[i]));     // what the wait guards
+            }
+            usleep(2000);                                           // the callbacks are running (blocked)
+            rel.dst = w + 12;
+            rel.val = 1;
+            double t0 = now_us();
+            CK(hipLaunchHostFunc(st[7], store_cb, &rel));           // the release arrives as a host function of ANOTHER stream
+            for (int i = 0; i < n_blocked; ++i) CK(hipStreamSynchronize(st[i]));
+            double dt = now_us() - t0;
+            int to = 0;
+            for (int i = 0; i < n_blocked; ++i) to += blk[i].timed_out;
+            printf("F %d stream(s) blocked in a host function, released by a host function on another stream: all done %.1f us after the release was "
+                   "enqueued, timed out %d (0 = callbacks of different streams do not serialise)\n", n_blocked, dt, to);
+            CK(hipDeviceSynchronize());
+        }
+        // the wait inside a callback vs the main thread waiting and then enqueueing: time from the release to the guarded copy's completion
+        for (int rep = 0; rep < 3; ++rep) {
+            w[12] = 0;
+            w[50] = 0;
+            blk[0].w = w + 12;
+            blk[0].want = 1;
+            CK(hipLaunchHostFunc(st[0], block_cb, &blk[0]));
+            CK(hipMemcpyAsync(dshm + 50, dvals + 60 + rep, 8, hipMemcpyDeviceToHost, st[0]));
+            usleep(1000);
+            double t0 = now_us();
+            __atomic_store_n(w + 12, 1, __ATOMIC_RELEASE);
+            double dt = host_wait(w + 50, 1060 + rep, t0);
+            CK(hipStreamSynchronize(st[0]));
+            w[12] = 0;
+            w[51] = 0;
+            usleep(1000);
+            double t1 = now_us();
+            __atomic_store_n(w + 12, 1, __ATOMIC_RELEASE);
+            host_wait(w + 12, 1, t1);                                // (the main thread sees the word ...)
+            CK(hipMemcpyAsync(dshm + 51, dvals + 70 + rep, 8, hipMemcpyDeviceToHost, st[1]));      // ... and only then enqueues the copy
+            double dt2 = host_wait(w + 51, 1070 + rep, t1);
+            CK(hipStreamSynchronize(st[1]));
+            printf("F release -> guarded 8-byte copy done: %.1f us with the wait inside a host function on the copy stream, %.1f us with the main "
+                   "thread waiting and then enqueueing\n", dt, dt2);
+        }
     }
     __atomic_store_n(w + 14, 1, __ATOMIC_RELEASE);                 // tell the child to leave
     int st = 0;
