@@ -217,18 +217,34 @@ def seoul_train_setup(pkg, dev, batch, mode, seed=1801, graphed=False, auto_grap
 
 
 def time_train_steps(step, steps, warmup):
-    """(ms per step wall clock with a sync on both sides, ms per step the host spent issuing it - i.e. without the final wait)."""
+    """(ms per step wall clock with a sync on both sides, ms per step the host spent issuing it - i.e. without the final wait).
+    r04: the median of up to five blocks (each at least 10 steps) with the garbage collector off inside a block - one host-side
+    stall inside a single block of a launch-bound step is worth tenths of a millisecond per step."""
+    import gc
+    gc.collect()
     for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    t_issue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    n_blocks = max(1, min(5, steps // 10))
+    per_block = steps // n_blocks
+    was = gc.isenabled()
+    gc.disable()
+    wall, issue = [], []
+    try:
+        for _ in range(n_blocks):
+            t0 = time.perf_counter()
+            for _ in range(per_block):
+                loss = step()
+            t_issue = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - t0) / per_block * 1e3)
+            issue.append(t_issue / per_block * 1e3)
+    finally:
+        if was:
+            gc.enable()
     assert torch.isfinite(loss).item(), "non-finite loss"
-    return el / steps * 1e3, t_issue / steps * 1e3, float(loss)
+    mid = sorted(range(n_blocks), key=lambda i: wall[i])[n_blocks // 2]
+    return wall[mid], issue[mid], float(loss)
 
 
 def cpu_train_baseline(coo_slices_cpu, n_user, model, ids, batch, n_threads, steps=5):
@@ -268,6 +284,9 @@ def cpu_train_baseline(coo_slices_cpu, n_user, model, ids, batch, n_threads, ste
 
 def train_secondary(pkg, dev, batch, mode, steps=30, warmup=5, graphed=False, auto_graph=True, eval_mode=False):
     """One labelled measurement of the reference's training step in one dropout mode."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                # (the previous secondary's graphs and pools are gone before this one builds its own)
     model, step, coo, _ = seoul_train_setup(pkg, dev, batch, mode, graphed=graphed, auto_graph=auto_graph, eval_mode=eval_mode)
     ms, ms_issue, loss = time_train_steps(step, steps, warmup)
     n_layer = len(TRAIN_CFG["layers"])

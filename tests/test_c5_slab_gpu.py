@@ -77,6 +77,10 @@ def test_c5_rank_slabs_of_eight():
                 m = (le + e) @ W1.double().T + 2 * b1.double() + (le * e) @ W2.double().T + b2.double()
                 m = torch.where(m >= 0, m, 0.2 * m)
                 np.testing.assert_allclose(carry[row].cpu().numpy(), m.cpu().numpy(), atol=2e-4, rtol=RTOL, err_msg=f"{tag} row {row}")
+                # ... and the block that goes into all_E (F.normalize, NGCF.py:144) at the forward tolerance itself: the carry's entries
+                # are O(1..30) here (random unit-variance operands, K = 256), its normalised row is what SURVEY 8c's atol is stated on
+                np.testing.assert_allclose(nrm[row].cpu().numpy(), (m / m.norm().clamp_min(1e-12)).cpu().numpy(), atol=ATOL, rtol=RTOL,
+                                           err_msg=f"{tag} normalised row {row}")
             del csr, LX, LY, LZ, carry, nrm
         del ur, uc, uv, ir, ic, iv, slabs
         if rank == 3:

@@ -480,3 +480,47 @@ def test_backward_through_the_sharded_propagation_ranks_share_one_gpu(world, col
         ret = mgr.dict()
         mp.spawn(_gpu_train_worker, args=(world, _free_port(), ret, collectives), nprocs=world, join=True)
         assert dict(ret) == {r: True for r in range(world)}
+
+
+def _p2p_collectives_worker(rank, world, port, ret):
+    """`P2PCollectives.all_gather` / `reduce_scatter` land their pulls in FRESH tensors.  The caching allocator hands a block out
+    again by stream order of the COMPUTE stream; the pulls run on copy streams - without the fence in `_stage` they could land while
+    kernels of the block's previous owner are still queued (the failure the exchange's self-test showed once in three runs with
+    five ranks, dist.py `selftest`).  Here the previous owner is made as unkind as possible: a tensor of exactly the result's size
+    with a long queue of kernels writing it, freed right before the collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NGCF_P2P_TIMEOUT_MS="20000")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seoul_tourism_recommendation_ngcf_amd import dist as nd
+        dev = torch.device("cuda:0")
+        m, d = 4096, 128
+        coll = nd.P2PCollectives(None, dev, world * m * d)
+        ok = True
+        for it in range(6):
+            send = torch.full((m, d), float(100 * it + rank), device=dev) + torch.arange(d, device=dev)
+            tmp = torch.empty((world * m, d), device=dev)           # the block `full` is about to get
+            for _ in range(150):
+                tmp.fill_(-7.0)                                    # queued behind each other on the compute stream
+            del tmp
+            full = coll.all_gather(send)
+            want = torch.cat([torch.full((m, d), float(100 * it + q), device=dev) + torch.arange(d, device=dev) for q in range(world)])
+            ok = ok and torch.equal(full, want)
+            part = torch.full((world * m, d), float(it + 1 + rank), device=dev)
+            tmp = torch.empty((world, m, d), device=dev)            # the block `slots` is about to get
+            for _ in range(150):
+                tmp.fill_(-9.0)
+            del tmp
+            own = coll.reduce_scatter(part)
+            ok = ok and torch.equal(own, torch.full((m, d), float(sum(it + 1 + q for q in range(world))), device=dev))
+        torch.cuda.synchronize()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_p2p_collectives_fence_their_fresh_destinations():
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_p2p_collectives_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+        assert dict(ret) == {0: True, 1: True, 2: True}

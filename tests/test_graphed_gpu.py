@@ -161,6 +161,7 @@ def test_unchanged_callers_get_the_graph_replay(dev):
                 auto(node_flag=False, **bad)
     auto.check_indices_now()                                           # the status word was reset by the raise
     plain.user_embedding.weight.data.copy_(auto.user_embedding.weight.data)
+    plain.invalidate_all_E()       # r04: a write through .data from outside bypasses the version counter the retained all_E watches
     same(eval_batch())
 
 

@@ -117,3 +117,67 @@ for W in (1, 2, 4, 8):
     print(f"W={W}: rank {r}: {csr_u.nnz + csr_it.nnz} stored entries, swept rows [{csr_it.swept_rows}, {csr_u.swept_rows}]; compute {ms:.3f} ms per layer "
           f"({n_layer * ms:.2f} ms per step, {base / ms:.2f}x the W=1 rank); exchange: {sent / 1e6:.1f} MB received per rank and layer "
           f"(partial-sum slices + carry rows) = {sent / max(W - 1, 1) / 153e9 * 1e3:.3f} ms with every peer on its own 153 GB/s link", flush=True)
+
+# ---- r04: what does NOT shrink with W - the per-pass floor of the W = 8 rank (the last loop's W, r, eb, ob still hold): the E0
+# copy of the local rows (skipped from the second pass on while the tables are unchanged: dist._propagate_bipartite `keep`), the
+# served row gathers over the exchange (owned rows -> exchange buffer, W blocks pulled, one select kernel) and BPR
+B, D = 1024, 512
+nu, ni = hi - lo, ob[r + 1] - ob[r]
+allE_u, allE_i = torch.randn((nu, D), device=dev) * 0.1, torch.randn((ni, D), device=dev) * 0.1
+uw, iw = torch.randn((U, d), device=dev), torch.randn((I, d), device=dev)
+status = torch.zeros(1, dtype=torch.int32, device=dev)
+gg = torch.Generator().manual_seed(3)
+ids = [torch.randint(0, hi_, (B,), generator=gg).to(dev) for hi_ in (U, I, I)]
+mine = torch.empty((3 * B, D), device=dev)
+slots = torch.empty((W, 3 * B, D), device=dev)
+own_idx = torch.cat([(torch.searchsorted(torch.tensor(eb, device=dev), ids[0], right=True) - 1).clamp(0, W - 1)] +
+                    [(torch.searchsorted(torch.tensor(ob, device=dev), t, right=True) - 1).clamp(0, W - 1) for t in ids[1:]]) * (3 * B) + torch.arange(3 * B, device=dev)
+crit = pkg.BPR(0.025, B)
+
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def e0_copy():
+    eng.copy_rows(uw[lo:hi], allE_u[:, :d])
+    eng.copy_rows(iw[ob[r]:ob[r + 1]], allE_i[:, :d])
+
+
+def owned():
+    at = 0
+    for table, ix, lo_, n_ in ((allE_u, ids[0], lo, nu), (allE_i, ids[1], ob[r], ni), (allE_i, ids[2], ob[r], ni)):
+        loc = (ix - lo_).contiguous()
+        _lib.check(lib.ngcf_gather_rows_f32(C.c_void_p(table.data_ptr()), D, D, C.c_void_p(loc.data_ptr()), B, 0, n_, C.c_void_p(mine[at:at + B].data_ptr()), D,
+                                            C.c_void_p(status.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        at += B
+
+
+def pulls_local():
+    for q in range(W):
+        slots[q].copy_(mine)
+
+
+def select_and_bpr():
+    out = eng.gather_rows(slots.view(W * 3 * B, D), own_idx, status)
+    return crit(out[:B], out[B:2 * B], out[2 * B:])
+
+
+t_e0, t_own, t_pull, t_sel = timeit(e0_copy), timeit(owned), timeit(pulls_local), timeit(select_and_bpr)
+layer_ms = ms
+print(f"W={W} rank {r} per-pass floor (us): E0 copy of the local rows {t_e0:.1f} (first pass only: retained afterwards), owned-row gathers into the "
+      f"exchange buffer {t_own:.1f}, select kernel + BPR {t_sel:.1f}; the {W} block pulls of {3 * B * D * 4 / 1e6:.1f} MB as LOCAL device-to-device copies "
+      f"{t_pull:.1f} (a stand-in: across xGMI they are {W - 1} SDMA copies on {W - 1} links at once, {3 * B * D * 4 / 153e9 * 1e6:.0f} us each at 153 GB/s) + "
+      f"one publish host function (24 us, profiles/r04_memops_lab.txt)", flush=True)
+floor_us = t_own + t_sel + 24 + 3 * B * D * 4 / 153e9 * 1e6 + 10
+print(f"step estimate at W={W}: 3 x {layer_ms:.3f} ms + floor {floor_us / 1e3:.3f} ms = {3 * layer_ms + floor_us / 1e3:.3f} ms, if the per-layer exchange hides under "
+      f"the products it overlaps (DESIGN.md 6.3); the one-GPU step is the driver's BENCH line", flush=True)
