@@ -219,6 +219,14 @@ int ngcf_copy_rows2_f32(const float *src, int64_t lds, float *dst, int64_t ldd, 
 int ngcf_copy_rows_indexed_f32(const float *src, int64_t lds, float *dst, int64_t ldd, const int64_t *idx, int64_t n_idx,
                                int64_t n_rows, int d, void *stream);
 
+/* HOST routine (r04): n draws of torch's CPU `bernoulli_(keep)` - what `nn.Dropout` draws on a CPU tensor, NGCF.py:93-100,142 -
+ * from the generator whose state bytes (`torch.get_rng_state()`, >= 5016 bytes, legacy mt19937 layout) are `rng_state`; the bytes
+ * are advanced in place exactly as torch advances its generator (two 32-bit outputs per element).  flags[i] (uint8, may be NULL) =
+ * kept, noise[i] (float, may be NULL) = kept ? scale : 0, *n_kept = count.  Host pointers.  Bit-identical to torch's own serial
+ * kernel (checked against it by the caller once per process), several times faster (vector loops, no lock per element). */
+int ngcf_torch_cpu_bernoulli(uint8_t *rng_state, int64_t state_bytes, int64_t n, double keep, uint8_t *flags, float *noise,
+                             float scale, int64_t *n_kept);
+
 /* ---- feature injection (NGCF.py:103-115) ---------------------------------------------- */
 /*
  * user_w[u_id[b], :] = user_w[u_id[b], :]*(1-r) + cat(age,sex,month,day,dow rows)[b, :]*r.

@@ -159,6 +159,58 @@ class _TrainGraphs:
         return outs
 
 
+_HOST_RNG = {"ok": None}
+
+
+def _host_rng_ok() -> bool:
+    """Whether `ngcf_torch_cpu_bernoulli` (csrc/hostrng.hip: torch's CPU `bernoulli_` stream regenerated in vector loops) may stand
+    in for torch's own serial kernel in this process: decided once, by drawing 4 099 elements both ways from copies of one
+    generator state - flags, kept count and the advanced state must all be equal.  (Another torch build may draw differently - an
+    MKL stream, another state layout: then the reference-mode masks keep coming from torch itself, at torch's speed.)"""
+    if _HOST_RNG["ok"] is None:
+        ok = False
+        try:
+            import ctypes as C
+            lib = _eng._lib.load()
+            g = torch.Generator(device="cpu").manual_seed(0x5EED)
+            torch.empty(3, dtype=torch.float32).uniform_(generator=g)          # an odd word position
+            st = g.get_state().clone()
+            n = 4099
+            flags = torch.empty(n, dtype=torch.uint8)
+            kept = C.c_int64()
+            rc = lib.ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), n, 0.7, flags.data_ptr(), None, 0.0, C.byref(kept))
+            want = torch.empty(n, dtype=torch.float64).bernoulli_(0.7, generator=g)
+            ok = (rc == 0 and torch.equal(flags.bool(), want != 0) and int(kept.value) == int((want != 0).sum())
+                  and torch.equal(st, g.get_state()))
+        except Exception:  # noqa: BLE001
+            ok = False
+        _HOST_RNG["ok"] = bool(ok) and os.environ.get("NGCF_HOST_RNG", "1") != "0"
+    return _HOST_RNG["ok"]
+
+
+def _reference_bernoulli(n: int, p_drop: float, noise_shape=None):
+    """`nn.Dropout(p_drop)` in training mode on a CPU tensor of n ones, drawn from torch's DEFAULT CPU generator exactly as the
+    reference draws it (NGCF.py:93-100 on float64 ones, NGCF.py:142 on the float32 activations; both take one 64-bit draw per
+    element): returns (keep flags uint8[n] or None, kept count, noise float32 `noise_shape` or None) - the flags for the node
+    dropout, the noise tensor (0 or 1/(1-p) as torch rounds it) for the message dropout."""
+    import ctypes as C
+    keep = 1.0 - float(p_drop)
+    if _host_rng_ok():
+        st = torch.get_rng_state()
+        flags = None if noise_shape is not None else torch.empty(n, dtype=torch.uint8)
+        noise = torch.empty(noise_shape, dtype=torch.float32) if noise_shape is not None else None
+        scale = float(torch.ones(1, dtype=torch.float32).div_(keep)) if noise is not None else 0.0
+        kept = C.c_int64()
+        _eng._lib.check(_eng._lib.load().ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), n, keep, None if flags is None else flags.data_ptr(),
+                                                                  None if noise is None else noise.data_ptr(), scale, C.byref(kept)))
+        torch.set_rng_state(st)
+        return flags, int(kept.value), noise
+    if noise_shape is not None:
+        return None, -1, torch.nn.functional.dropout(torch.ones(noise_shape, dtype=torch.float32), p=p_drop, training=True)
+    flags = torch.nn.functional.dropout(torch.ones(n, dtype=torch.float64), p=p_drop, training=True).type(torch.bool)
+    return flags, int(flags.sum()), None
+
+
 def _spmm_mode() -> int:
     """SpMM kernel choice for the cached Laplacians (include/ngcf_hip.h, ngcf_csr_set_mode); NGCF_SPMM_MODE overrides."""
     return int(os.environ.get("NGCF_SPMM_MODE", "3"))
@@ -384,17 +436,14 @@ class NGCF(nn.Module):
             if node_ref:
                 # one flag per entry of the matrix as the previous layers left it (cumulative, NGCF.py:126); the thinned CSR is a
                 # device compaction of the previous one into buffers this module keeps from step to step (ngcf_csr_filter)
-                keep = torch.nn.functional.dropout(torch.ones(src.nnz, dtype=torch.float64), p=self.node_dropout,
-                                                   training=True).type(torch.bool)
-                n_kept = int(keep.sum())
+                keep, n_kept, _ = _reference_bernoulli(src.nnz, self.node_dropout)
                 keep = keep.to(dev)
                 src = src.filtered(keep, None, n_kept, reuse=self._filt.pop(("L", year_idx, k), None))
                 self._filt[("L", year_idx, k)] = src
                 csrs.append(src)
                 flags.append(keep)
             if mess_ref and drop[k] > 0:
-                noise = torch.nn.functional.dropout(torch.ones((N, widths[k + 1]), dtype=torch.float32),
-                                                    p=drop[k], training=True)
+                _, _, noise = _reference_bernoulli(N * widths[k + 1], drop[k], (N, widths[k + 1]))
                 masks.append(noise.to(dev, non_blocking=False))
             else:
                 masks.append(None)
@@ -439,15 +488,13 @@ class NGCF(nn.Module):
         idx = L._indices().to(dev)
         val = L._values().to(device=dev, dtype=torch.float32)
         for k in range(self.n_layer):
-            mask = torch.nn.functional.dropout(torch.ones(val.numel(), dtype=torch.float64),
-                                               p=self.node_dropout, training=True).type(torch.bool).to(dev)
+            mask = _reference_bernoulli(int(val.numel()), self.node_dropout)[0].to(dev).bool()
             idx, val = idx[:, mask], val[mask]
             order = torch.sort(idx[0], stable=True).indices
             csrs.append(_eng.LaplacianCSR.from_coo(idx[0][order], idx[1][order], val[order], N, N))
             kept.append((idx, val))
             if mess_ref and drop[k] > 0:
-                noise = torch.nn.functional.dropout(torch.ones((N, widths[k + 1]), dtype=torch.float32), p=drop[k], training=True)
-                masks.append(noise.to(dev, non_blocking=False))
+                masks.append(_reference_bernoulli(N * widths[k + 1], drop[k], (N, widths[k + 1]))[2].to(dev, non_blocking=False))
             else:
                 masks.append(None)
         return csrs, (lambda: [self._transposed_csr(i, v)[0] for i, v in kept]), masks if mess_ref else None

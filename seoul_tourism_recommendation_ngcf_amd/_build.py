@@ -13,7 +13,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("csr.hip", "spmm.hip", "spmm_swept.hip", "dense.hip", "ops.hip", "backward.hip", "comm.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("csr.hip", "spmm.hip", "spmm_swept.hip", "dense.hip", "ops.hip", "backward.hip", "comm.hip", "hostrng.hip")]
 HEADERS = [os.path.join(os.path.dirname(PKG_DIR), "include", "ngcf_hip.h"), os.path.join(CSRC, "common.h"),
            os.path.join(CSRC, "spmm_device.h")]
 LIB = os.path.join(PKG_DIR, "libngcf_hip.so")

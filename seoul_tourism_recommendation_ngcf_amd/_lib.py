@@ -97,6 +97,7 @@ PROTOTYPES = {
     "ngcf_p2p_wait_acks": (C.c_int, [_vp, C.c_int, _u64, C.c_double]),
     "ngcf_p2p_fence": (C.c_int, [_vp, _vp]),
     "ngcf_p2p_join": (C.c_int, [_vp, _vp]),
+    "ngcf_torch_cpu_bernoulli": (C.c_int, [_vp, _i64, _i64, C.c_double, _vp, _vp, _f32, C.POINTER(_i64)]),
     "ngcf_p2p_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64), C.c_int]),
     "ngcf_sum_slots_f32": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp]),
 }

@@ -43,7 +43,7 @@ import torch.distributed as dist
 
 from . import _lib
 from . import engine as _eng
-from .autograd import held_elsewhere
+from .autograd import E0Cache
 
 SCHEME_NOTES = {
     "allgather": "row partition (users and items, cut by stored entries) + RCCL all-gather of the carry per layer, user slab "
@@ -727,6 +727,24 @@ class ShardedPropagation:
         if self.backend == "cabi":
             self._cabi = _CabiAllGather(group, dev)
 
+    # this rank's rows of all_E (NGCF.py:147-149): stored under the attribute names autograd.E0Cache looks at, so that the same
+    # hold detection decides whether the previous pass's buffer may be written again
+    @property
+    def allE_u(self):
+        return self.__dict__.get("all_users_emb")
+
+    @allE_u.setter
+    def allE_u(self, v):
+        self.all_users_emb = v
+
+    @property
+    def allE_i(self):
+        return self.__dict__.get("all_items_emb")
+
+    @allE_i.setter
+    def allE_i(self, v):
+        self.all_items_emb = v
+
     def item_pos(self, item: torch.Tensor) -> torch.Tensor:
         """bipartite scheme: item index -> position in the padded item numbering (owner-major)."""
         return padded_item_pos(item, self.ib, self.mi)
@@ -872,21 +890,23 @@ class ShardedPropagation:
         d0 = widths[0]
         iw = m.item_embedding.weight.detach()
         uwp, iwp = m.user_embedding.weight, m.item_embedding.weight
-        # r04: the result buffers of the previous pass are written again - and their block 0 (E0, NGCF.py:120) NOT copied again -
-        # while both tables are the same tensors at the same version and nobody else holds the previous result (held_elsewhere:
-        # a caller who kept it gets a fresh pair, as before).  At W = 8 that is the rank's share of the 0.21 ms E0 copy per pass.
+        # r04: ONE result buffer [nu + ni, D] (users first; the three served gathers then read one table in one launch), and the
+        # previous pass's buffer is written again - its block 0 (E0, NGCF.py:120) NOT copied again - while both tables are the same
+        # tensors at the same version and nobody else holds the previous result (autograd.E0Cache.only_the_modules: a caller who
+        # kept it gets a fresh buffer, as before).  At W = 8 that is the rank's share of the E0 copy per pass (23 us of a 2 ms step).
         e0_tag = (uwp.data_ptr(), int(uwp._version), iwp.data_ptr(), int(iwp._version), tuple(widths), nu, ni)
-        keep = (getattr(self, "_allE_tag", None) == e0_tag and getattr(self, "allE_u", None) is not None
-                and not self.allE_u.requires_grad and not held_elsewhere(self.allE_u) and not held_elsewhere(self.allE_i))
+        cache = self.__dict__.setdefault("_e0", E0Cache())
+        keep = cache.tag == e0_tag and cache.only_the_modules(self)
         if keep:
-            allE_u, allE_i = self.allE_u, self.allE_i
+            allE = cache.all_E
         else:
-            self.allE_u = self.allE_i = None
-            allE_u = torch.empty((nu, D), dtype=torch.float32, device=self.dev)   # this rank's users
-            allE_i = torch.empty((ni, D), dtype=torch.float32, device=self.dev)   # the items this rank owns
-            _eng.copy_rows(uwp.detach()[lo:lo + nu], allE_u[:, :d0])
-            _eng.copy_rows(iw[self.ib[r]:self.ib[r + 1]], allE_i[:, :d0])
-            self._allE_tag = e0_tag
+            cache.invalidate()
+            self._all_E = self.all_users_emb = self.all_items_emb = None
+            allE = torch.empty((nu + ni, D), dtype=torch.float32, device=self.dev)
+            _eng.copy_rows(uwp.detach()[lo:lo + nu], allE[:nu, :d0])
+            _eng.copy_rows(iw[self.ib[r]:self.ib[r + 1]], allE[nu:, :d0])
+            cache.all_E, cache.tag = allE, e0_tag
+        allE_u, allE_i = allE[:nu], allE[nu:]                       # this rank's users / the items this rank owns
         # layer-0 item replica from the replicated parameter table (padded numbering): local copies, no communication - and none at
         # all while the table is the same tensor at the same version as in the previous pass (inference loops)
         ei = self._buf(("ei", 0), (PI, ld(d0)))[:, :d0]
@@ -982,7 +1002,7 @@ class ShardedPropagation:
                     ei = nxt_ei[:, :d_out]
             eu = cu
             off += d_out
-        self.allE_u, self.allE_i = allE_u, allE_i
+        self._all_E, self.all_users_emb, self.all_items_emb = allE, allE_u, allE_i
         return allE_u, allE_i
 
     def _gather_async(self, region: torch.Tensor, send: torch.Tensor):
@@ -1119,20 +1139,53 @@ class ShardedPropagation:
     def invalidate_e0(self):
         """Forget that block 0 of the retained result buffers and the layer-0 item replica hold the current tables: the next pass
         copies them again.  Needed only after a write to an embedding table through `.data` (invisible to the version counters)."""
-        self._allE_tag = self._ei0_tag = None
+        self._ei0_tag = None
+        if "_e0" in self.__dict__:
+            self._e0.invalidate()
+
+    def _local_index(self, ix: torch.Tensor, lo: int) -> torch.Tensor:
+        """ix - lo as a contiguous int64 device tensor, computed once per index tensor OBJECT and version (a loop over fixed
+        batches pays no launch for it)."""
+        import weakref
+        memo = self.__dict__.setdefault("_loc_idx", {})
+        key = (id(ix), int(ix._version), int(lo))
+        hit = memo.get(key)
+        if hit is not None and hit[0]() is ix:
+            return hit[1]
+        if len(memo) > 16:
+            memo.clear()
+        loc = (ix.to(device=self.dev, dtype=torch.int64) - lo).contiguous()
+        memo[key] = (weakref.ref(ix), loc)
+        return loc
 
     def _owned_rows(self, out, sets):
         """The rows of the batch this rank owns, gathered into their positions of `out` [sum of sizes, D]; positions other ranks own
-        are left alone (ngcf_gather_rows_f32 skips ids outside the range: the status word of that call is a throw-away)."""
+        are left alone (the gather kernels skip ids outside the range: the status word of that call is a throw-away).  One launch
+        when this rank's rows live in one buffer (the bipartite inference path), else one per index vector."""
         lib = _lib.load()
         D = int(out.shape[1])
         scrap = self._buf(("scrap_status",), (1,)).view(torch.int32)
-        at = 0
+        base = self.__dict__.get("_all_E")
+        one = (base is not None and all(t._base is base for t, _, _, _ in sets) and len(sets) <= 3
+               and self.__dict__.get("all_users_emb") is sets[0][0])
         with _eng._on(self.dev):
+            if one:
+                args, at = [], 0
+                for table, ix, lo, n_rows in sets:
+                    b = int(ix.numel())
+                    row_off = 0 if table is self.all_users_emb else int(self.all_users_emb.shape[0])
+                    args += [_eng._ptr(self._local_index(ix, lo)) if b and n_rows else None, b if n_rows else 0, row_off, n_rows,
+                             _eng._ptr(out[at:at + b]) if b and n_rows else None]
+                    at += b
+                args += [None, 0, 0, 0, None] * (3 - len(sets))
+                _lib.check(lib.ngcf_gather_rows3_f32(_eng._ptr(base), _eng._row_major_ld(base, "all_E"), D, *args, D, _eng._ptr(scrap),
+                                                     _eng._stream()))
+                return
+            at = 0
             for table, ix, lo, n_rows in sets:
                 b = int(ix.numel())
                 if n_rows and b:
-                    loc = (ix.to(torch.int64) - lo).contiguous()
+                    loc = self._local_index(ix, lo)
                     _lib.check(lib.ngcf_gather_rows_f32(_eng._ptr(table), _eng._row_major_ld(table, "table"), D, _eng._ptr(loc), b, 0, n_rows,
                                                         _eng._ptr(out[at:at + b]), D, _eng._ptr(scrap), _eng._stream()))
                 at += b

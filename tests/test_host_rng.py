@@ -1,0 +1,64 @@
+"""`ngcf_torch_cpu_bernoulli` (csrc/hostrng.hip, r04): the reference's dropout masks come from torch's default CPU generator
+(`nn.Dropout` on CPU tensors, /root/reference/model/NGCF.py:93-100,142).  The routine regenerates that mt19937 stream in vector
+loops; it must be torch's own serial kernel bit for bit - flags, noise values, kept count AND the generator state afterwards - at
+every word position (odd positions, block boundaries) and size.  Host code: runs without a GPU."""
+import ctypes as C  # noqa: I001
+
+import pytest
+import torch
+
+import importlib
+
+from seoul_tourism_recommendation_ngcf_amd import _lib
+
+ngcf_mod = importlib.import_module("seoul_tourism_recommendation_ngcf_amd.NGCF")      # (the package re-exports the class under this name)
+
+
+def _ours(n, keep, want_noise):
+    lib = _lib.load()
+    st = torch.get_rng_state().clone()
+    flags = torch.empty(n, dtype=torch.uint8)
+    noise = torch.empty(n, dtype=torch.float32) if want_noise else None
+    scale = float(torch.ones(1).div_(keep)) if want_noise else 0.0
+    k = C.c_int64()
+    _lib.check(lib.ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), n, keep, flags.data_ptr(), noise.data_ptr() if want_noise else None,
+                                            scale, C.byref(k)))
+    return st, flags, noise, int(k.value)
+
+
+@pytest.mark.parametrize("pre", [0, 3, 617, 1247, 624 * 3 + 1])
+@pytest.mark.parametrize("n", [1, 7, 311, 312, 313, 20_000])
+def test_host_draws_are_torchs_own(pre, n):
+    for p_drop, dtype in ((0.3, torch.float64), (0.1, torch.float32)):
+        torch.manual_seed(100 + pre)
+        if pre:
+            torch.rand(pre)                              # float draws take ONE word each: odd positions, several blocks in
+        st1, flags, noise, kept = _ours(n, 1 - p_drop, dtype == torch.float32)
+        want = torch.nn.functional.dropout(torch.ones(n, dtype=dtype), p_drop, True)     # what the reference calls
+        assert torch.equal(flags.bool(), want != 0) and kept == int((want != 0).sum())
+        assert torch.equal(st1, torch.get_rng_state())                                   # the generator is where torch left its own
+        if noise is not None:
+            assert torch.equal(noise, want)                                              # 0 or 1/(1-p), rounded as torch rounds it
+
+
+def test_module_helper_consumes_the_default_generator_like_the_reference():
+    """`NGCF._reference_bernoulli` (what the reference-mode forward calls): same masks and the same generator state as two
+    `F.dropout` calls in the reference's order - the node mask on float64 ones, then the message noise on float32 ones."""
+    assert ngcf_mod._host_rng_ok()
+    torch.manual_seed(77)
+    want_keep = torch.nn.functional.dropout(torch.ones(5003, dtype=torch.float64), 0.3, True) != 0
+    want_noise = torch.nn.functional.dropout(torch.ones((37, 65), dtype=torch.float32), 0.1, True)
+    after = torch.get_rng_state()
+    torch.manual_seed(77)
+    keep, n_kept, _ = ngcf_mod._reference_bernoulli(5003, 0.3)
+    _, _, noise = ngcf_mod._reference_bernoulli(37 * 65, 0.1, (37, 65))
+    assert torch.equal(keep.bool(), want_keep) and n_kept == int(want_keep.sum()) and torch.equal(noise, want_noise)
+    assert torch.equal(torch.get_rng_state(), after)
+
+
+def test_bad_state_is_refused():
+    lib = _lib.load()
+    st = torch.get_rng_state().clone()
+    assert lib.ngcf_torch_cpu_bernoulli(st.data_ptr(), 100, 5, 0.5, None, None, 0.0, None) != 0        # too short for the layout
+    st[8:12] = 0                                                                                      # left = 0: not a state torch produces
+    assert lib.ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), 5, 0.5, None, None, 0.0, None) != 0

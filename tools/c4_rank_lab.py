@@ -123,7 +123,8 @@ for W in (1, 2, 4, 8):
 # served row gathers over the exchange (owned rows -> exchange buffer, W blocks pulled, one select kernel) and BPR
 B, D = 1024, 512
 nu, ni = hi - lo, ob[r + 1] - ob[r]
-allE_u, allE_i = torch.randn((nu, D), device=dev) * 0.1, torch.randn((ni, D), device=dev) * 0.1
+allE = torch.randn((nu + ni, D), device=dev) * 0.1                 # one result buffer, users first (dist._propagate_bipartite)
+allE_u, allE_i = allE[:nu], allE[nu:]
 uw, iw = torch.randn((U, d), device=dev), torch.randn((I, d), device=dev)
 status = torch.zeros(1, dtype=torch.int32, device=dev)
 gg = torch.Generator().manual_seed(3)
@@ -153,13 +154,13 @@ def e0_copy():
     eng.copy_rows(iw[ob[r]:ob[r + 1]], allE_i[:, :d])
 
 
-def owned():
-    at = 0
-    for table, ix, lo_, n_ in ((allE_u, ids[0], lo, nu), (allE_i, ids[1], ob[r], ni), (allE_i, ids[2], ob[r], ni)):
-        loc = (ix - lo_).contiguous()
-        _lib.check(lib.ngcf_gather_rows_f32(C.c_void_p(table.data_ptr()), D, D, C.c_void_p(loc.data_ptr()), B, 0, n_, C.c_void_p(mine[at:at + B].data_ptr()), D,
-                                            C.c_void_p(status.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        at += B
+loc_idx = [(ids[0] - lo).contiguous(), (ids[1] - ob[r]).contiguous(), (ids[2] - ob[r]).contiguous()]   # cached per index tensor in the product
+
+
+def owned():                                                    # ONE launch: the three gathers of the rows this rank owns
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.ngcf_gather_rows3_f32(p(allE), D, D, p(loc_idx[0]), B, 0, nu, p(mine[:B]), p(loc_idx[1]), B, nu, ni, p(mine[B:2 * B]),
+                                         p(loc_idx[2]), B, nu, ni, p(mine[2 * B:]), D, p(status), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
 def pulls_local():
