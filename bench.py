@@ -755,7 +755,7 @@ def main():
             out["p2p_host"] = None if not st else {**st, "host_blocked_ms_per_step": st["host_blocked_ms"] / args.steps,
                                                    "note": "the exchange runs no kernel and moves rows on copy engines; its cost is host "
                                                            "time in bounded waits for the peers' publications - zero when they are there"}
-            out["p2p_error"] = getattr(sh, "p2p_error", None)     # why the CU-free transport was not used (None: it was, or was not asked for)
+            out["p2p_error"] = getattr(sh, "p2p_error", None) or getattr(sh, "gather_p2p_error", None)   # why the CU-free transport was not used (None: it was, or was not asked for)
             out["secondary_overrun"] = False                      # True only on a line the watchdog printed
         return out
 

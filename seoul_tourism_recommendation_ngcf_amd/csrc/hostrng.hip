@@ -44,6 +44,23 @@ __attribute__((always_inline)) inline uint32_t temper(uint32_t y)
     y ^= y >> 18;
     return y;
 }
+// the elements of one block: pairs of tempered words -> kept or not.  All integer: x = v * 2^-53 < keep  <=>  v < keep * 2^53
+// <=> v < T with T = ceil(keep * 2^53) (v is an integer; the product is exact, a power-of-two scaling).  No u64 -> double conversion
+// (AVX2 has none, AVX-512F neither), no branch in the loop body: FLAGS / NOISE are compile-time.
+template <bool FLAGS, bool NOISE>
+__attribute__((always_inline)) inline int64_t classify(const uint32_t *__restrict__ w, int pairs, uint64_t T, uint8_t *__restrict__ flags,
+                                                       float *__restrict__ noise, float scale)
+{
+    int64_t kept = 0;
+    for (int k = 0; k < pairs; ++k) {                          // first word = high half (make64BitsFrom32Bits(random1, random2))
+        const uint64_t v = ((uint64_t)(w[2 * k] & 0x1fffffu) << 32) | w[2 * k + 1];
+        const int keep_it = v < T;
+        kept += keep_it;
+        if (FLAGS) flags[k] = (uint8_t)keep_it;
+        if (NOISE) noise[k] = keep_it ? scale : 0.f;
+    }
+    return kept;
+}
 }  // namespace
 
 // n Bernoulli(keep) draws from the generator whose state bytes are `rng_state` (torch.get_rng_state(), updated in place):
@@ -67,7 +84,10 @@ extern "C" __attribute__((target_clones("avx512f", "avx2", "default"))) int ngcf
         memcpy(&w, rng_state + kOffState + 8 * (size_t)j, 8);
         s[j] = (uint32_t)w;
     }
+    if (!(keep >= 0.0 && keep <= 1.0)) return fail(NGCF_ERR_ARG, "torch_cpu_bernoulli: keep probability %g not in [0, 1]", keep);
     const double thresh = keep * 9007199254740992.0;           // keep * 2^53: exact (a power of two), so x < keep <=> v < thresh
+    uint64_t T = (uint64_t)thresh;
+    if ((double)T < thresh) ++T;                               // ceil: v < thresh <=> v < T for integer v
     int pos = left == 1 ? kN : (int)next;                      // index of the next word; kN = "regenerate first"
     int64_t kept = 0, i = 0;
     uint32_t w[kN + 2];                                        // tempered words of one block, behind a carried half pair
@@ -83,13 +103,10 @@ extern "C" __attribute__((target_clones("avx512f", "avx2", "default"))) int ngcf
         pos += take;
         have += take;
         const int pairs = have / 2;
-        for (int k = 0; k < pairs; ++k) {                      // first word = high half (make64BitsFrom32Bits(random1, random2))
-            const uint64_t v = ((uint64_t)(w[2 * k] & 0x1fffffu) << 32) | w[2 * k + 1];
-            const int keep_it = (double)v < thresh;
-            kept += keep_it;
-            if (flags) flags[i + k] = (uint8_t)keep_it;
-            if (noise) noise[i + k] = keep_it ? scale : 0.f;
-        }
+        if (flags && noise) kept += classify<true, true>(w, pairs, T, flags + i, noise + i, scale);
+        else if (flags) kept += classify<true, false>(w, pairs, T, flags + i, nullptr, scale);
+        else if (noise) kept += classify<false, true>(w, pairs, T, nullptr, noise + i, scale);
+        else kept += classify<false, false>(w, pairs, T, nullptr, nullptr, scale);
         i += pairs;
         if (have & 1) w[0] = w[have - 1];
         have &= 1;

@@ -1227,8 +1227,17 @@ class ShardedPropagation:
                     gx.wait_acks(reg_, max(last, 0))
                 gx.close()
             self._gx_region = need
-            self._gx = gx = P2PExchange(self.group, self.dev, 2 * need)
-            self._gx_calls = 0
+            self._gx, self._gx_calls = None, 0
+            try:       # (a failure is a failure on every rank: the constructor and the self-test share their verdicts)
+                gx = P2PExchange(self.group, self.dev, max(2 * need, 1024))
+                if not gx.selftest():
+                    err = getattr(gx, "last_error", "self-test failed")
+                    gx.close()
+                    raise RuntimeError(err)
+                self._gx = gx
+            except Exception as exc:  # noqa: BLE001
+                self.gather_p2p_error = repr(exc)[:300]           # the gathers keep the all-reduce; bench.py quotes the reason
+                return None
         reg = self._gx_calls % 2
         self._gx_calls += 1
         seq = self._gx_calls
@@ -1260,9 +1269,11 @@ class ShardedPropagation:
             sets.append((self.allE_i, neg_item, i_lo, i_n))
         D = int(self.allE_u.shape[1])
         sizes = [int(ix.numel()) for _, ix, _, _ in sets]
-        if self.backend == "p2p" and sum(sizes) > 0 and os.environ.get("NGCF_DIST_GATHER", "p2p") == "p2p":
+        outs = None
+        if (self.backend == "p2p" and sum(sizes) > 0 and os.environ.get("NGCF_DIST_GATHER", "p2p") == "p2p"
+                and getattr(self, "gather_p2p_error", None) is None):
             outs = self._gather_p2p(sets, sizes, D, u_id, pos_item, neg_item)
-        else:
+        if outs is None:
             buf = torch.zeros((sum(sizes), D), dtype=torch.float32, device=self.dev)
             self._owned_rows(buf, sets)
             dist.all_reduce(buf, group=self.group)
