@@ -115,10 +115,12 @@ class E0Cache:
                 tuple(item_w.shape), tuple(widths), str(dev))
 
     def _counts(self, owner):
-        """(Python references to all_E, to each of the module's two views, tensors on the storage) - read the same way here and in
-        the calibration below, so the constants of this interpreter / torch build cancel out."""
+        """(Python references to all_E and to each of the module's two views, C++ references to the three tensors - a DLPack capsule
+        or another extension holding one of them shows up there -, tensors on the storage) - read the same way here and in the
+        calibration below, so the constants of this interpreter / torch build cancel out."""
         d = owner.__dict__
         return (sys.getrefcount(self.all_E), sys.getrefcount(d["all_users_emb"]), sys.getrefcount(d["all_items_emb"]),
+                self.all_E._use_count(), d["all_users_emb"]._use_count(), d["all_items_emb"]._use_count(),
                 torch._C._storage_Use_Count(self.all_E.untyped_storage()._cdata))
 
     _free = {}

@@ -366,6 +366,57 @@ __global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float *__r
     }
 }
 
+// A NARROW block of input columns (d_in <= 4: the 1..3 columns the reference's widths leave beyond a multiple of 128 - 130 -> 2,
+// 515 -> 3; autograd._bwd_weight cuts the layer into blocks of 128 input columns).  The matrix-core kernel above multiplies the
+// zero padding of such a block along at the full block's price (0.78 ms for the two last columns of C3's 130-wide first layer);
+// this is a pass over dM with the 2 x d_in operand values of a row as scalars: thread o of a 128-thread group adds
+// dM[row][o] * (LE + E)[row][c] and dM[row][o] * (LE * E)[row][c] over its workgroup's rows (coalesced rows of dM, a fixed order),
+// two row groups per workgroup combined through LDS; the same compact per-workgroup partials, so the same reduction follows.
+__global__ __launch_bounds__(256) void bwd_weight_narrow_kernel(const float *__restrict__ dM, int64_t ldM, const float *__restrict__ LE,
+                                                                int64_t ldLE, const float *__restrict__ E, int64_t ldE, int64_t n_rows,
+                                                                int d_in, int d_out, float *__restrict__ partial,
+                                                                float *__restrict__ partial_bias)
+{
+    __shared__ float comb[9][kBwM];
+    const int o = threadIdx.x & (kBwM - 1), half = threadIdx.x >> 7;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, p[4] = {0.f, 0.f, 0.f, 0.f}, b = 0.f;
+    const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n_rows ? r0 + per : n_rows;
+    // four rows per step and row group: four independent loads of dM in flight per thread (rows past the end contribute zeros)
+    for (int64_t row = r0 + 4 * half; row < r1; row += 8) {
+        float m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (o < d_out && row + q < r1) ? dM[(row + q) * ldM + o] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t rq = row + q < r1 ? row + q : r1 - 1;                 // (clamped: m[q] is zero there)
+            b += m[q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < d_in) {
+                    const float le = LE[rq * ldLE + c], e = E[rq * ldE + c];    // the same address in every lane: one broadcast load
+                    s[c] = fmaf(m[q], le + e, s[c]);
+                    p[c] = fmaf(m[q], le * e, p[c]);
+                }
+        }
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) comb[c][o] = s[c], comb[4 + c][o] = p[c];
+        comb[8][o] = b;
+    }
+    __syncthreads();
+    if (half == 1 || o >= d_out) return;
+    float *out = partial + (int64_t)blockIdx.x * d_out * 2 * d_in;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < d_in) {
+            out[o * 2 * d_in + c] = s[c] + comb[c][o];
+            out[o * 2 * d_in + d_in + c] = p[c] + comb[4 + c][o];
+        }
+    partial_bias[(int64_t)blockIdx.x * kBwM + o] = b + comb[8][o];
+}
+
 extern "C" int64_t ngcf_bwd_weight_workspace_bytes(void)
 {
     return (int64_t)kBwWGs * kBwM * kBwN * sizeof(float) + (int64_t)kBwWGs * kBwM * sizeof(float) + 256;
@@ -393,6 +444,16 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
     // back (256 of them: 33 MB and 116 us for a 65 x 130 gradient)
     const int64_t n_blocks = (n_rows + kBwRows - 1) / kBwRows;
     const int n_wg = (int)std::min<int64_t>(kBwWGs, std::max<int64_t>(1, (n_blocks + 1) / 2));
+    if (d_in <= 4 && n_rows >= 65536) {       // a narrow remainder block of a large matrix: no matrix cores for 2 x d_in columns
+        const int n_nwg = kBwWGs * 4;         // memory-bound: four workgroups per CU
+        float *nbias = partial + (int64_t)n_nwg * d_out * 2 * d_in;          // (behind the weight partials: 1024 x 128 floats fit easily)
+        bwd_weight_narrow_kernel<<<n_nwg, 256, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, partial, nbias);
+        LAUNCH_CHECK();
+        const int total_n = d_out * 2 * d_in + ((gb1 || gb2) ? d_out : 0);
+        bwd_weight_reduce_kernel<<<(total_n + 63) / 64, 256, 0, stream>>>(partial, nbias, n_nwg, d_in, d_out, gW1, ld1, gW2, ld2, gb1, gb2);
+        LAUNCH_CHECK();
+        return NGCF_OK;
+    }
     if (al)
         bwd_weight_kernel<true><<<n_wg, 512, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, P, partial, partial_bias);
     else

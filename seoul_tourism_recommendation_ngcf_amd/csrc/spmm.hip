@@ -248,22 +248,29 @@ __global__ void tail_unpack_kernel(const typename VecT<TW>::type *__restrict__ T
 // four of them per wave, four independent (col, val, gather) triples in flight per lane: a 50-entry user row is one pass of
 // its group.  One wave per row (spmm_kernel<4,1,1,1>) is latency-bound at ~0.5 us per row: 1.0 ms per product on C3, this
 // form 0.3 ms.
-template <int TW>
+// DROP (r04): device-side node dropout - an entry counts iff edge_keep(row, column) says so, the same test the row-wise and the
+// swept kernels apply (the training step's 130-wide products ran their two tail columns through the row-wise VEC = 1 kernel:
+// 1.55 ms per product at C3 against 0.8 here).
+template <int TW, bool DROP>
 __global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                                         const float *__restrict__ vals, int64_t n_rows,
                                                         const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
                                                         int64_t n_seg, int64_t seg_blocks, int seg_len,
                                                         const typename VecT<TW>::type *__restrict__ T,
-                                                        typename VecT<TW>::type *__restrict__ out, typename VecT<TW>::type *__restrict__ partial)
+                                                        typename VecT<TW>::type *__restrict__ out, typename VecT<TW>::type *__restrict__ partial,
+                                                        EdgeDrop dr_in)
 {
     using V = typename VecT<TW>::type;
     const int unit = threadIdx.x >> 4, l = threadIdx.x & 15;
-    int64_t begin = 0, end = 0;
+    int64_t begin = 0, end = 0, my_row = 0;
     V *dst = nullptr;
+    EdgeDropR dr;
+    if (DROP) dr = resolve_drop(dr_in);
     if ((int64_t)blockIdx.x < seg_blocks) {
         const int64_t s = (int64_t)blockIdx.x * 16 + unit;
         if (s < n_seg) {
             begin = seg_begin[s];
+            my_row = seg_row[s];
             const int64_t row_end = rowptr[seg_row[s] + 1];
             end = begin + seg_len < row_end ? begin + seg_len : row_end;
             dst = partial + s;
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restric
         if (row < n_rows) {
             begin = rowptr[row];
             end = rowptr[row + 1];
+            my_row = row;
             dst = out + row;
             if (end - begin > seg_len) dst = nullptr, end = begin;   // cut row: produced from its segments
         }
@@ -282,7 +290,13 @@ __global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restric
         const int64_t e1 = e + 16, e2 = e + 32, e3 = e + 48;
         const bool k1 = e1 < end, k2 = e2 < end, k3 = e3 < end;
         const int c0 = colidx[e], c1 = k1 ? colidx[e1] : 0, c2 = k2 ? colidx[e2] : 0, c3 = k3 ? colidx[e3] : 0;
-        const float v0 = vals[e], v1 = k1 ? vals[e1] : 0.f, v2 = k2 ? vals[e2] : 0.f, v3 = k3 ? vals[e3] : 0.f;
+        float v0 = vals[e], v1 = k1 ? vals[e1] : 0.f, v2 = k2 ? vals[e2] : 0.f, v3 = k3 ? vals[e3] : 0.f;
+        if (DROP) {
+            v0 = edge_keep(dr, my_row, c0) ? v0 : 0.f;
+            v1 = edge_keep(dr, my_row, c1) ? v1 : 0.f;
+            v2 = edge_keep(dr, my_row, c2) ? v2 : 0.f;
+            v3 = edge_keep(dr, my_row, c3) ? v3 : 0.f;
+        }
         const V t0 = T[c0], t1 = T[c1], t2 = T[c2], t3 = T[c3];
         a0 = vfma(v0, t0, a0);
         a1 = vfma(v1, t1, a1);
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(256) void spmm_tail_kernel(const int64_t *__restric
 // one tail product through its compact tables (workspace: [partial sums ... | T_in [n_cols] | T_out [n_rows]] as 16-byte slots)
 template <int TW>
 static int launch_tail(const ngcf_csr *c, const float *E, int64_t ldE, int tail, float *out, int64_t ldo, void *workspace,
-                       int64_t workspace_bytes, hipStream_t stream)
+                       int64_t workspace_bytes, hipStream_t stream, const EdgeDrop &dr)
 {
     using V = typename VecT<TW>::type;
     uintptr_t end = reinterpret_cast<uintptr_t>(workspace) + (uintptr_t)workspace_bytes;
@@ -311,8 +325,12 @@ static int launch_tail(const ngcf_csr *c, const float *E, int64_t ldE, int tail,
     const int64_t seg_blocks = (c->n_seg + 15) / 16, row_blocks = (c->n_rows + 15) / 16;
     if (seg_blocks + row_blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm: too many rows for one launch");
     prof_mark(stream, 0);
-    spmm_tail_kernel<TW><<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(
-        c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, Tin, Tout, tpart);
+    if (dr.n > 0)
+        spmm_tail_kernel<TW, true><<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(
+            c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, Tin, Tout, tpart, dr);
+    else
+        spmm_tail_kernel<TW, false><<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(
+            c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, seg_blocks, c->seg_len, Tin, Tout, tpart, dr);
     LAUNCH_CHECK();
     if (c->n_heavy > 0) {
         spmm_fixup_kernel<TW><<<dim3((unsigned)((c->n_heavy + 3) / 4)), 256, 0, stream>>>(
@@ -573,10 +591,10 @@ int spmm_dispatch(const ngcf_csr *c, const float *E, int64_t ldE, int d, float *
             const int rc = spmm_dispatch(c, E, ldE, main, out, ldo, workspace, workspace_bytes, stream, dr);
             if (rc != NGCF_OK) return rc;
             const int tail = d - main;
-            if (tail <= 4 && dr.n == 0 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !ngcf_opts().no_tail_table) {
-                if (tail == 1) return launch_tail<1>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream);
-                if (tail == 2) return launch_tail<2>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream);
-                return launch_tail<4>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream);
+            if (tail <= 4 && workspace && workspace_bytes >= ngcf_spmm_workspace_bytes(c, d) && !ngcf_opts().no_tail_table) {
+                if (tail == 1) return launch_tail<1>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream, dr);
+                if (tail == 2) return launch_tail<2>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream, dr);
+                return launch_tail<4>(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream, dr);
             }
             return spmm_dispatch(c, E + main, ldE, tail, out + main, ldo, workspace, workspace_bytes, stream, dr);
         }

@@ -167,7 +167,10 @@ def test_bpr_backward_matches_golden_grads(dev):
 
 @pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(0, 16, 8, False), (33, 7, 5, False), (1000, 65, 64, False),
                                                         (9001, 128, 128, False), (70000, 130 - 2, 96, True), (3000, 130, 200, False),
-                                                        (777, 515, 64, True)])
+                                                        (777, 515, 64, True),
+                                                        # r04: from 65 536 rows up the 1..3 columns beyond a multiple of 128 (130, 515-wide
+                                                        # first layers) run on the narrow kernel: 2, 3 and 1 remainder columns, ragged row count
+                                                        (70001, 130, 128, False), (66000, 515, 96, True), (65537, 129, 128, False)])
 def test_weight_gradient_kernel_matches_fp64(n_rows, d_in, d_out, strided, dev):
     """gW = dM^T . [LE+E | LE*E] and gb = column sums of dM (MFMA kernel, csrc/backward.hip) against fp64 from the definition (NGCF.py:131-136),
     incl. widths that are not multiples of 32 or 4, a row count that is not a multiple of the block, strided operands

@@ -36,6 +36,9 @@ def test_a_result_somebody_else_holds_is_never_reused(padded):
     alias = o.all_users_emb.detach()
     assert not c.only_the_modules(o)
     del alias
+    capsule = torch.utils.dlpack.to_dlpack(o.all_items_emb)            # an exported view (no new Python reference, no new storage user)
+    assert not c.only_the_modules(o)
+    del capsule
     copy_ = o.all_items_emb[torch.tensor([0, 1])]
     clone = o.all_users_emb.clone()
     assert c.only_the_modules(o) and copy_.shape[0] == 2 and clone.shape[0] == 6
