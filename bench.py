@@ -395,7 +395,8 @@ def c3_train_measure(pkg, lib, dev, lap, n_user, n_item, nnz, batch, steps, warm
     model = pkg.NGCF(d0, list(layers), c["node_dropout"], list(c["mess_dropout"]), 1.0, [lap], nd, batch, dev).to(dev).train()
     model.check_indices = False
     model.node_dropout_mode = model.mess_dropout_mode = "device"
-    opt = torch.optim.Adam(model.parameters(), lr=c["lr"])
+    fused = os.environ.get("NGCF_BENCH_ADAM_FUSED") == "1"        # lab: torch's fused Adam (one pass over the tables) instead of the reference's default
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], **({"fused": True} if fused else {}))
     crit = pkg.BPR(c["wd"], batch)
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     ids = {k: torch.randint(0, hi, (batch,), generator=g).to(dev)
@@ -429,7 +430,7 @@ def c3_train_measure(pkg, lib, dev, lap, n_user, n_item, nnz, batch, steps, warm
             "spmm_products_timed": int(n_l.value), "spmm_products_per_step": n_l.value / max(steps, 1),
             "mean_spmm_product_ms": tot.value / max(n_l.value, 1),
             "spmm_model_a_bytes": {str(d): spmm_model_a_bytes(csr.nnz, N, N, d) for d in sorted({d0, *layers})},
-            "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30, "model": model, "ids": ids, "d0": d0, "layers": list(layers),
+            "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30, "adam_fused": fused, "model": model, "ids": ids, "d0": d0, "layers": list(layers),
             "note": f"experiment.py:45-58 at scale: embed {d0} -> {list(layers)}, node dropout {c['node_dropout']} + message dropout "
                     f"{list(c['mess_dropout'])} (device masks), batch {batch}, Adam lr {c['lr']}, BPR wd {c['wd']}, node_flag=True, train mode; "
                     "step = forward + BPR + backward + Adam.step; the products timed are the full SpMMs of the step (3 forward L.E + the "
