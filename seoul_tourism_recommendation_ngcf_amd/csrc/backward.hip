@@ -382,13 +382,13 @@ __global__ __launch_bounds__(256) void bwd_weight_narrow_kernel(const float *__r
     float s[4] = {0.f, 0.f, 0.f, 0.f}, p[4] = {0.f, 0.f, 0.f, 0.f}, b = 0.f;
     const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n_rows ? r0 + per : n_rows;
-    // four rows per step and row group: four independent loads of dM in flight per thread (rows past the end contribute zeros)
-    for (int64_t row = r0 + 4 * half; row < r1; row += 8) {
-        float m[4];
+    // eight rows per step and row group: eight independent loads of dM in flight per thread (rows past the end contribute zeros)
+    for (int64_t row = r0 + 8 * half; row < r1; row += 16) {
+        float m[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[q] = (o < d_out && row + q < r1) ? dM[(row + q) * ldM + o] : 0.f;
+        for (int q = 0; q < 8; ++q) m[q] = (o < d_out && row + q < r1) ? dM[(row + q) * ldM + o] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const int64_t rq = row + q < r1 ? row + q : r1 - 1;                 // (clamped: m[q] is zero there)
             b += m[q];
 #pragma unroll
@@ -445,7 +445,7 @@ extern "C" int ngcf_layer_bwd_weight_f32(const float *dM, int64_t ldM, const flo
     const int64_t n_blocks = (n_rows + kBwRows - 1) / kBwRows;
     const int n_wg = (int)std::min<int64_t>(kBwWGs, std::max<int64_t>(1, (n_blocks + 1) / 2));
     if (d_in <= 4 && n_rows >= 65536) {       // a narrow remainder block of a large matrix: no matrix cores for 2 x d_in columns
-        const int n_nwg = kBwWGs * 4;         // memory-bound: four workgroups per CU
+        const int n_nwg = kBwWGs * 8;         // memory-bound: eight workgroups per CU
         float *nbias = partial + (int64_t)n_nwg * d_out * 2 * d_in;          // (behind the weight partials: 1024 x 128 floats fit easily)
         bwd_weight_narrow_kernel<<<n_nwg, 256, 0, stream>>>(dM, ldM, LE, ldLE, E, ldE, n_rows, d_in, d_out, partial, nbias);
         LAUNCH_CHECK();
@@ -599,6 +599,253 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_input_kernel(const float *__
     }
 }
 
+
+// ---- r04: the same product with the weights RESIDENT in LDS (the structure of layer_dense_resident_kernel, dense.hip) --------
+// The staged kernel above runs at 37 % of the fp32 matrix peak at C3 (1.23 ms per 1.1 M-row layer): its two K loops over staged
+// chunks (8 barriers per 128 rows, dM read twice, the W chunks re-staged by every workgroup) and its epilogue (2 loads + 2 stores per
+// output element) run one after the other, so matrix time and memory time add up.  Here [W1 | W2] for one panel of 128 input
+// columns - K x 256 floats, 128 KB at K = 128 - is loaded into LDS ONCE per persistent workgroup (8 waves, one workgroup per CU);
+// a wave owns 32 rows outright: each lane reads the 16-byte pieces of ITS row of dM straight from global memory into the MFMA A
+// layout, two chunks (of 16 k) ahead in two fixed register sets, and every k-pair feeds EIGHT accumulator tiles (dS and dP of the
+// four 32-column tiles) - dM is read once, there is no barrier after the prologue, and the next tile's first chunks are requested
+// before the epilogue of the current one.  The k order per output element is the staged kernel's (ascending k-pairs), so the
+// results are bit-identical to it.
+static constexpr int kBiResWaves = 8, kBiResWGs = 256, kBiResDC = 16;
+#ifndef NGCF_BI_EPI_DEPTH
+#define NGCF_BI_EPI_DEPTH 2
+#endif
+
+// Wr[k][0..127] = W1[k][t * 32 + li] at [li * 4 + t], Wr[k][128..255] the same of W2 (zero outside the matrices): a lane's four
+// tile values of one k are 16 contiguous bytes, a wave's reads of one k are 512 contiguous bytes (conflict-free ds_read_b128)
+__global__ void bwd_input_pack_resident_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int d_out, int d_in, int col0,
+                                               int k_pad, float *__restrict__ Wr)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k_pad * 256; i += gridDim.x * blockDim.x) {
+        const int k = i >> 8, x = i & 255, half = x >> 7, y = x & 127;
+        const int col = col0 + (y & 3) * 32 + (y >> 2);
+        Wr[i] = (k < d_out && col < d_in) ? (half ? W2 : W1)[(int64_t)k * d_in + col] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kBiResWaves * 64) void layer_bwd_input_resident_kernel(
+    const float *__restrict__ dM, int64_t ldM, int64_t n_rows, int d_out, const float *__restrict__ Wr, int n_chunks,
+    const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ E, int64_t ldE, int d_in, int col0, float *__restrict__ dLE,
+    int64_t ldd, float *__restrict__ dE, int64_t lde)
+{
+    extern __shared__ float Wres[];                // [n_chunks * 16][256]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    {
+        const bw_f32x4 *src = reinterpret_cast<const bw_f32x4 *>(Wr);
+        bw_f32x4 *dst = reinterpret_cast<bw_f32x4 *>(Wres);
+        const int n4 = n_chunks * kBiResDC * 256 / 4;
+        for (int i = tid; i < n4; i += kBiResWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    const int d4 = (d_out + 3) & ~3;
+    const float *W = Wres + li * 4;
+    const int last = n_chunks - 1;
+    const int64_t tile_step = (int64_t)gridDim.x * kBiResWaves;
+    auto row_of = [&](int64_t t) {                 // the lane's row of tile t (rows past the end re-read the last row, never stored)
+        const int64_t g = t * 32 + li;
+        return g < n_rows ? g : n_rows - 1;
+    };
+    // the lane's two 16-byte pieces of a chunk: dM at columns c*16 + lh*4 (a) and c*16 + 8 + lh*4 (b); columns past d_out are
+    // re-read from the row's last float4 and zeroed at use
+    auto fetch = [&](const float *row, int c, bw_f32x4 &a, bw_f32x4 &b) {
+        const int ca = c * kBiResDC + lh * 4, cb = ca + 8;
+        a = *reinterpret_cast<const bw_f32x4 *>(row + (ca < d4 ? ca : d4 - 4));
+        b = *reinterpret_cast<const bw_f32x4 *>(row + (cb < d4 ? cb : d4 - 4));
+    };
+    bw_f32x4 a0, b0, a1, b1;                        // two chunks of look-ahead in two fixed register sets (every prefetch unconditional)
+    int64_t tile = (int64_t)blockIdx.x * kBiResWaves + wave;
+    {
+        const float *r0 = dM + row_of(tile < n_tiles ? tile : 0) * ldM;
+        fetch(r0, 0, a0, b0);
+        fetch(r0, last < 1 ? last : 1, a1, b1);
+    }
+    for (; tile < n_tiles; tile += tile_step) {
+        const int64_t row0 = tile * 32;
+        const float *m_row = dM + row_of(tile) * ldM;
+        bw_f32x16 accS[4], accP[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accS[t][r] = 0.f, accP[t][r] = 0.f;
+        auto chunk_mfma = [&](int c, bw_f32x4 a, bw_f32x4 b) {
+            const int ca = c * kBiResDC + lh * 4, cb = ca + 8;
+            if (cb + 4 > d_out) {                   // only the last chunk of a width that is not a multiple of 16
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (ca + q >= d_out) a[q] = 0.f;
+                    if (cb + q >= d_out) b[q] = 0.f;
+                }
+            }
+            const float *wc = W + (int64_t)c * kBiResDC * 256;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bw_f32x4 av = kb ? b : a;
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) {
+                    const float *wk = wc + (kb * 8 + lh * 4 + sx) * 256;
+                    const bw_f32x4 v1 = *reinterpret_cast<const bw_f32x4 *>(wk);
+                    const bw_f32x4 v2 = *reinterpret_cast<const bw_f32x4 *>(wk + 128);
+                    accS[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v1.x, accS[0], 0, 0, 0);
+                    accS[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v1.y, accS[1], 0, 0, 0);
+                    accS[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v1.z, accS[2], 0, 0, 0);
+                    accS[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v1.w, accS[3], 0, 0, 0);
+                    accP[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v2.x, accP[0], 0, 0, 0);
+                    accP[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v2.y, accP[1], 0, 0, 0);
+                    accP[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v2.z, accP[2], 0, 0, 0);
+                    accP[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sx], v2.w, accP[3], 0, 0, 0);
+                }
+            }
+        };
+        int c = 0;
+        for (; c + 1 < n_chunks; c += 2) {
+            {
+                const bw_f32x4 ua = a0, ub = b0;
+                fetch(m_row, c + 2 < last ? c + 2 : last, a0, b0);          // in flight under two chunks of MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                chunk_mfma(c, ua, ub);
+            }
+            {
+                const bw_f32x4 ua = a1, ub = b1;
+                fetch(m_row, c + 3 < last ? c + 3 : last, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                chunk_mfma(c + 1, ua, ub);
+            }
+        }
+        if (c < n_chunks) chunk_mfma(c, a0, b0);
+        {   // the next tile's first two chunks, ahead of this tile's epilogue (the last tile of a wave re-reads its own)
+            const float *rn = dM + row_of(tile + tile_step < n_tiles ? tile + tile_step : tile) * ldM;
+            fetch(rn, 0, a0, b0);
+            fetch(rn, last < 1 ? last : 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: dLE = dS + dP * E, dE = dS + dP * LE.  Full tiles take a path without per-element tests: behind a branch the
+        // compiler cannot move a load ahead of the stores of the row before it, and an epilogue of 16 dependent load -> FMA -> store
+        // rounds is 16 memory latencies per tile (the first version: 1.16 ms per layer, matrix pipe 43 % busy); here the E / LE values
+        // of two row groups are in flight while the previous group is combined and stored.
+        if (row0 + 32 <= n_rows && col0 + 128 <= d_in) {
+            const int64_t rbase = row0 + 4 * lh;
+            const float *pe = E + rbase * ldE + col0 + li, *pl = LE + rbase * ldLE + col0 + li;
+            float *ple = dLE + rbase * ldd + col0 + li, *pde = dE + rbase * lde + col0 + li;
+            constexpr int DEPTH = NGCF_BI_EPI_DEPTH;   // row groups of E / LE values in flight
+            float ev[DEPTH][4], lv[DEPTH][4];
+            auto ld_r = [&](int r, float (&e)[4], float (&l)[4]) {
+                const int64_t ro = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e[t] = pe[ro * ldE + t * 32], l[t] = pl[ro * ldLE + t * 32];
+            };
+#pragma unroll
+            for (int r = 0; r < DEPTH - 1; ++r) ld_r(r, ev[r], lv[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r + DEPTH - 1 < 16) ld_r(r + DEPTH - 1, ev[(r + DEPTH - 1) % DEPTH], lv[(r + DEPTH - 1) % DEPTH]);
+                const int64_t ro = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float ds = accS[t][r], dp = accP[t][r];
+                    ple[ro * ldd + t * 32] = fmaf(dp, ev[r % DEPTH][t], ds);
+                    pde[ro * lde + t * 32] = fmaf(dp, lv[r % DEPTH][t], ds);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t grow = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (grow >= n_rows) continue;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = col0 + t * 32 + li;
+                if (col < d_in) {
+                    const float ds = accS[t][r], dp = accP[t][r];
+                    dLE[grow * ldd + col] = fmaf(dp, E[grow * ldE + col], ds);
+                    dE[grow * lde + col] = fmaf(dp, LE[grow * ldLE + col], ds);
+                }
+            }
+        }
+    }
+}
+
+// The 1..4 input columns a 130- / 515-wide first layer leaves beyond its panels of 128: per row the dot products of its dM row with
+// columns c of W1 and W2 (K values each), one wave per four rows - lane l holds k = l and l + 64 of the weight columns in registers -
+// and the same epilogue.  A pass over dM (0.56 GB at C3) instead of a 160-column panel of the staged kernel.
+__global__ __launch_bounds__(256) void layer_bwd_input_narrow_kernel(const float *__restrict__ dM, int64_t ldM, int64_t n_rows, int d_out,
+                                                                     const float *__restrict__ W1, const float *__restrict__ W2,
+                                                                     const float *__restrict__ LE, int64_t ldLE, const float *__restrict__ E,
+                                                                     int64_t ldE, int d_in, int col0, int ncols, float *__restrict__ dLE,
+                                                                     int64_t ldd, float *__restrict__ dE, int64_t lde)
+{
+    const int lane = threadIdx.x & 63;
+    float w1[2][4], w2[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = lane + 64 * h;
+            const bool ok = k < d_out && c < ncols;
+            w1[h][c] = ok ? W1[(int64_t)k * d_in + col0 + c] : 0.f;
+            w2[h][c] = ok ? W2[(int64_t)k * d_in + col0 + c] : 0.f;
+        }
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // four rows per step: eight independent loads of dM in flight per lane (one row per step is one memory latency per row: 0.64 ms
+    // at C3 for a pass that moves 0.56 GB)
+    for (int64_t row4 = wave0 * 4; row4 < n_rows; row4 += n_waves * 4) {
+        float m0[4], m1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = row4 + q < n_rows ? row4 + q : n_rows - 1;
+            m0[q] = lane < d_out ? dM[row * ldM + lane] : 0.f;
+            m1[q] = lane + 64 < d_out ? dM[row * ldM + lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = row4 + q;
+            // v[0..3] = dS of columns 0..3, v[4..7] = dP: eight partial dot products per lane, reduced over the wave with a halving
+            // butterfly - at every step a lane keeps half of its values and takes the partner's for those (10 exchanges, not 48)
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] = fmaf(m1[q], w1[1][c], m0[q] * w1[0][c]);
+                v[4 + c] = fmaf(m1[q], w2[1][c], m0[q] * w2[0][c]);
+            }
+            float u[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {              // lanes with bit 5 clear keep v[0..3], the others v[4..7]
+                const float mine = (lane & 32) ? v[4 + i] : v[i], theirs = (lane & 32) ? v[i] : v[4 + i];
+                u[i] = mine + __shfl_xor(theirs, 32);
+            }
+            float t2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {              // bit 4 clear: u[0..1], set: u[2..3]
+                const float mine = (lane & 16) ? u[2 + i] : u[i], theirs = (lane & 16) ? u[i] : u[2 + i];
+                t2[i] = mine + __shfl_xor(theirs, 16);
+            }
+            float x;
+            {
+                const float mine = (lane & 8) ? t2[1] : t2[0], theirs = (lane & 8) ? t2[0] : t2[1];
+                x = mine + __shfl_xor(theirs, 8);
+            }
+            x += __shfl_xor(x, 4);
+            x += __shfl_xor(x, 2);
+            x += __shfl_xor(x, 1);
+            // lane's value: index = (bit5 ? 4 : 0) + (bit4 ? 2 : 0) + (bit3 ? 1 : 0) of v; lanes 0, 8, 16, 24 hold dS of columns 0..3 and
+            // lanes 32, 40, 48, 56 hold dP of the same columns: pair them up through one more exchange
+            const float dp = __shfl(x, (lane & 31) + 32);
+            const int c = ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+            if (row < n_rows && lane < 32 && (lane & 7) == 0 && c < ncols) {
+                const int col = col0 + c;
+                dLE[row * ldd + col] = fmaf(dp, E[row * ldE + col], x);
+                dE[row * lde + col] = fmaf(dp, LE[row * ldLE + col], x);
+            }
+        }
+    }
+}
+
 extern "C" int64_t ngcf_layer_bwd_input_workspace_bytes(int d_out)
 {
     if (d_out <= 0) return -1;
@@ -624,6 +871,35 @@ extern "C" int ngcf_layer_bwd_input_f32(const float *dM, int64_t ldM, int64_t n_
     const int n_chunks = (d_out + NGCF_BI_KC - 1) / NGCF_BI_KC;
     const int64_t blocks = (n_rows + kBiRows - 1) / kBiRows;
     if (blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "layer_bwd_input: too many rows");
+    // r04: large matrices at K <= 128 - panels of 128 input columns on the weights-resident kernel, a remainder of 1..4 columns
+    // (the reference's 130- / 515-wide first layers) on the narrow kernel
+    const int k_chunks = (d_out + kBiResDC - 1) / kBiResDC;
+    const bool resident = ngcf_opts().bwd_input_resident && d_out <= 128 && d_out >= 4 && n_rows >= 2 * 32 * kBiResWaves * kBiResWGs &&
+                          need >= (int64_t)k_chunks * kBiResDC * 256 * (int64_t)sizeof(float) + 256;
+    if (resident && d_out <= 128) {
+        static bool attr_set[kMaxDevices] = {};      // the attribute is per device
+        const int dev_i = current_device_slot();
+        if (!attr_set[dev_i]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_input_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+            attr_set[dev_i] = true;
+        }
+        const size_t lds = (size_t)k_chunks * kBiResDC * 256 * sizeof(float);
+        int col0 = 0;
+        for (; col0 < d_in && d_in - col0 > 4; col0 += 128) {
+            bwd_input_pack_resident_kernel<<<64, 256, 0, stream>>>(W1, W2, d_out, d_in, col0, k_chunks * kBiResDC, Wp);
+            LAUNCH_CHECK();
+            layer_bwd_input_resident_kernel<<<dim3(kBiResWGs), kBiResWaves * 64, lds, stream>>>(dM, ldM, n_rows, d_out, Wp, k_chunks, LE, ldLE, E,
+                                                                                               ldE, d_in, col0, dLE, ldd, dE, lde);
+            LAUNCH_CHECK();
+        }
+        if (col0 < d_in) {
+            layer_bwd_input_narrow_kernel<<<dim3(kBiResWGs * 8), 256, 0, stream>>>(dM, ldM, n_rows, d_out, W1, W2, LE, ldLE, E, ldE, d_in, col0,
+                                                                                  d_in - col0, dLE, ldd, dE, lde);
+            LAUNCH_CHECK();
+        }
+        return NGCF_OK;
+    }
     for (int col0 = 0; col0 < d_in;) {      // panels of 128 input columns, the last one up to 160 (stream-ordered re-use of Wp)
         const int left = d_in - col0;
         const int wcols = left > 128 && left <= 160 ? 160 : 128;

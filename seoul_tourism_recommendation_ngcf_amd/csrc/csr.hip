@@ -39,6 +39,7 @@ const OptField kOptFields[] = {
     {"dense_small_tiles", &NgcfOptions::dense_small_tiles, nullptr},
     {"dense_il_lab", &NgcfOptions::dense_il_lab, nullptr},
     {"dense_tall", &NgcfOptions::dense_tall, nullptr},
+    {"bwd_input_resident", &NgcfOptions::bwd_input_resident, nullptr},
     {"slice_max_mb", &NgcfOptions::slice_max_mb, nullptr},
     {"swept_lpe", &NgcfOptions::swept_lpe, nullptr},
     {"swept_waves", &NgcfOptions::swept_waves, nullptr},

@@ -216,6 +216,42 @@ def test_fused_input_gradient_kernel_vs_torch(n_rows, d_in, d_out, strided, dev)
     np.testing.assert_allclose(dE.cpu().numpy(), (dS + dP * LE.double()).cpu().numpy(), atol=2e-6 * max(scale, 1.0), rtol=2e-5)
 
 
+@pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(131072 + 37, 128, 128, False), (140001, 130, 128, True), (133000, 96, 65, False),
+                                                        (131072, 515, 64, True), (150000, 131, 100, False)])
+def test_resident_input_gradient_kernel_is_bit_identical_to_the_staged_one(n_rows, d_in, d_out, strided, dev, lib_options):
+    """r04: from 131 072 rows up (K = d_out <= 128) the input gradients run on `layer_bwd_input_resident_kernel` ([W1 | W2] of a
+    128-column panel resident in LDS, dM read once, no barrier after the prologue) plus `layer_bwd_input_narrow_kernel` for the
+    1..4 columns beyond the last panel.  Same k order per output element as the staged kernel: the panels are bit-identical to it;
+    the narrow columns (plain dot products, another order) within rounding; everything against fp64."""
+    from seoul_tourism_recommendation_ngcf_amd import autograd as ag
+    eng = _pkg().engine
+    g = torch.Generator().manual_seed(n_rows + d_in)
+    ldm = (d_out + 31) // 32 * 32                                      # dM as _bwd_pre hands it over: rows padded to 32 floats, padding NOT zeroed
+    dM = torch.full((n_rows, ldm), float("nan"), device=dev)[:, :d_out]
+    dM.copy_((torch.randn((n_rows, d_out), generator=g) * 0.3).to(dev))
+    W1, W2 = ((torch.randn((d_out, d_in), generator=g) * 0.1).to(dev) for _ in range(2))
+    if strided:
+        LE = (torch.randn((n_rows, d_in + 30), generator=g) * 0.5).to(dev)[:, :d_in]
+        E = (torch.randn((n_rows, d_in + 7), generator=g) * 0.5).to(dev)[:, 3:3 + d_in]
+    else:
+        LE, E = ((torch.randn((n_rows, d_in), generator=g) * 0.5).to(dev) for _ in range(2))
+    ws = eng.Workspace()
+    got = ag._bwd_input(dM, W1, W2, LE, E, ws)
+    lib_options(bwd_input_resident=0)
+    want = ag._bwd_input(dM, W1, W2, LE, E, ws)                         # the staged kernel
+    lib_options(bwd_input_resident=1)
+    n_panel = d_in if d_in % 128 == 0 or d_in % 128 > 4 else d_in // 128 * 128      # columns that ran on the resident kernel
+    for a, b in zip(got, want):
+        assert torch.equal(a[:, :n_panel], b[:, :n_panel])
+        if n_panel < d_in:
+            torch.testing.assert_close(a[:, n_panel:], b[:, n_panel:], rtol=1e-5, atol=1e-6)
+    rows = torch.cat([torch.arange(0, 64), torch.randint(0, n_rows, (512,), generator=g), torch.arange(n_rows - 40, n_rows)]).to(dev)
+    dS, dP = dM[rows].double() @ W1.double(), dM[rows].double() @ W2.double()
+    scale = max(float(dS.abs().max()), 1.0)
+    np.testing.assert_allclose(got[0][rows].cpu().numpy(), (dS + dP * E[rows].double()).cpu().numpy(), atol=2e-6 * scale, rtol=2e-5)
+    np.testing.assert_allclose(got[1][rows].cpu().numpy(), (dS + dP * LE[rows].double()).cpu().numpy(), atol=2e-6 * scale, rtol=2e-5)
+
+
 @pytest.mark.parametrize("node_mode", [None, "reference", "device"])
 def test_row_sparse_last_layer_backward_equals_the_dense_path(node_mode, dev, monkeypatch):
     """The last layer's backward on the <= 3 B gathered rows only (compacted dense kernels + ngcf_spmm_t_rows_f32 for
