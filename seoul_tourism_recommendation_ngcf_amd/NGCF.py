@@ -726,7 +726,9 @@ class NGCF(nn.Module):
         g = self._train_graphs.pop(key, None)
         if g is not None and not g.intact():                           # a baked buffer was replaced: these graphs are dead
             g = None
-        if getattr(self, "_seed_state", None) is not None and self._seed_state_src != torch.initial_seed():
+        draws = bool((node_flag and self.node_dropout) or
+                     (self.training and self.mess_dropout is not None and any(float(p) > 0 for p in self.mess_dropout[:self.n_layer])))
+        if draws and getattr(self, "_seed_state", None) is not None and self._seed_state_src != torch.initial_seed():
             if g is not None:
                 self._train_graphs[key] = g
             return None                                                # re-seeded since the last draw: this call draws eagerly (and re-seeds in place)

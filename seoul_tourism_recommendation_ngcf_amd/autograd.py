@@ -50,30 +50,8 @@ def _write_e0(owner, user_w, item_w, all_E, U, d0):
     return all_E[:, :d0]
 
 
-def _ref_counts(t):
-    return sys.getrefcount(t), torch._C._storage_Use_Count(t.untyped_storage()._cdata)
-
-
 class _Probe:
     pass
-
-
-def _calibrate():
-    """What `_ref_counts(owner.attr)` reads for a tensor that only `owner.attr` references (interpreter-specific constants)."""
-    o = _Probe()
-    o.t = torch.empty(1)
-    return _ref_counts(o.t)
-
-
-_FREE_COUNTS = _calibrate()
-
-
-def held_elsewhere(t: torch.Tensor) -> bool:
-    """Call as `held_elsewhere(owner.attr)`: True when anything besides that one attribute references the tensor object, or any
-    other tensor (a view, a detached alias) shares its storage.  A retained result buffer is overwritten only when this is False:
-    a caller who kept the previous result keeps it intact, as with a fresh allocation per call.  (Same call depth as the
-    calibration above: the counts include this function's own parameter.)"""
-    return (sys.getrefcount(t), torch._C._storage_Use_Count(t.untyped_storage()._cdata)) != _FREE_COUNTS
 
 
 class E0Cache:
