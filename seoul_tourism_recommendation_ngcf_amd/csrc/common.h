@@ -64,6 +64,7 @@ struct NgcfOptions {
     // dense.hip
     int dense_direct = 1;          // NGCF_DENSE_DIRECT: 0 never, 1 up to 8 192 rows, 2 at any row count
     int dense_resident = 1;        // NGCF_DENSE_RESIDENT: 0 keeps the staged kernel; (LAB) 2: layer_dense_resident_il_kernel where it applies
+    int dense_resident_min_rows = 106496;  // NGCF_DENSE_RESIDENT_MIN_ROWS: rows from which the weights-resident kernel runs (65 536 = one round of its 2 048 waves; measured cross-over, profiles/r04_dense_rows_lab.txt)
     int dense_small_tiles = 1;     // NGCF_DENSE_SMALL_TILES: 32-row tiles for <= 128 output columns on <= 16 384 rows
     int dense_tall = 1;            // NGCF_DENSE_TALL: 256 / 512 output columns as 96-row x 128-column workgroups: 0 never, 1 where measured faster, 2 always
     int dense_il_lab = 0;          // NGCF_DENSE_IL_LAB (LAB): the interleaved kernel taken apart: 1 no stores, 2 no loads, 3 neither

@@ -36,6 +36,7 @@ const OptField kOptFields[] = {
     {"fork_min", nullptr, &NgcfOptions::fork_min},
     {"dense_direct", &NgcfOptions::dense_direct, nullptr},
     {"dense_resident", &NgcfOptions::dense_resident, nullptr},
+    {"dense_resident_min_rows", &NgcfOptions::dense_resident_min_rows, nullptr},
     {"dense_small_tiles", &NgcfOptions::dense_small_tiles, nullptr},
     {"dense_il_lab", &NgcfOptions::dense_il_lab, nullptr},
     {"dense_tall", &NgcfOptions::dense_tall, nullptr},

@@ -1530,7 +1530,7 @@ extern "C" int ngcf_layer_dense_f32(const float *LE, int64_t ldLE, const float *
         const int resident = ngcf_opts().dense_resident;
         const int64_t lds_bytes = (int64_t)n_chunks * NGCF_KC * 128 * (int64_t)sizeof(float);
         if (resident && dop == 128 && al && ldLE >= align_up(d_in, 4) && ldEs >= align_up(d_in, 4) && d_in >= 4 &&
-            lds_bytes <= 150 * 1024 && n_rows >= 2 * 32 * kResWaves * kResWGs) {
+            lds_bytes <= 150 * 1024 && n_rows >= (int64_t)ngcf_opts().dense_resident_min_rows) {
             static bool attr_set[kMaxDevices] = {};      // the attribute is per device
             const int dev_i = current_device_slot();
             if (!attr_set[dev_i]) {

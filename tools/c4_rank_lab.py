@@ -113,6 +113,25 @@ for W in (1, 2, 4, 8):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     base = base or ms
+
+    def _t(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        for _ in range(n):
+            fn()
+        b_.record()
+        torch.cuda.synchronize()
+        return a_.elapsed_time(b_) / n
+    t_a = _t(lambda: eng.spmm(csr_it, eu, out=part, ws=ws))
+    t_bs = _t(lambda: eng.spmm(csr_u, ei, ws=ws))
+    t_b = _t(lambda: eng.layer_fused(csr_u, ei, eu, W1, b1, W2, b2, cu, nu_, ws))
+    t_c = _t(lambda: eng.layer_dense(le_own, ei[r * mi:(r + 1) * mi], W1, b1, W2, b2, ci, ni_, ws))
+    print(f"    parts at W={W}: A (item partial sums, {csr_it.nnz} entries -> {PI} rows from {hi - lo} local users) {t_a:.3f} ms; B product alone "
+          f"({csr_u.nnz} entries, {hi - lo} rows from the {PI}-row replica) {t_bs:.3f} ms, B with its dense half {t_b:.3f} ms; C (dense half of {mi} owned items) {t_c:.3f} ms; "
+          f"a perfect 1/W of the one-GPU product would be {2.96 / W / 2:.3f} ms per half", flush=True)
     sent = 2 * (W - 1) * mi * d * 4
     print(f"W={W}: rank {r}: {csr_u.nnz + csr_it.nnz} stored entries, swept rows [{csr_it.swept_rows}, {csr_u.swept_rows}]; compute {ms:.3f} ms per layer "
           f"({n_layer * ms:.2f} ms per step, {base / ms:.2f}x the W=1 rank); exchange: {sent / 1e6:.1f} MB received per rank and layer "
