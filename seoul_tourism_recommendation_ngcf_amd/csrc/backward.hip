@@ -116,6 +116,10 @@ extern "C" int ngcf_segment_sum_rows_f32(const float *g, int64_t ldg, int d, con
 
 // ---- normalise + dropout + LeakyReLU backward: (dN, dC, C) -> dM, one wave per row ------------
 // forward: A = leaky(M); C = keep ? A/(1-p) : 0; N = C / max(|C|, eps)    (NGCF.py:140-144)
+// VEC = 2 (r04): a lane owns the column pairs 2 lane, 2 lane + 128, .. (8-byte accesses: at d = 128 one load per operand and row
+// instead of two; same arithmetic per element and the same order in the two row sums - lanes hold other columns, the wave sum is a
+// sum over all of them either way - so only the association of those two sums differs from VEC = 1).
+template <int VEC>
 __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restrict__ dN, int64_t ldn,
                                                             const float *__restrict__ dC, int64_t ldc,
                                                             const float *__restrict__ C, int64_t ldC, int64_t n_rows,
@@ -133,9 +137,12 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
     float den = 1.f, ydot = 0.f;
     if (g) {
         float ss = 0.f, dot = 0.f;
-        for (int j = lane; j < d; j += 64) {
-            ss = fmaf(c[j], c[j], ss);
-            dot = fmaf(c[j], g[j], dot);
+        for (int j = lane * VEC; j < d; j += 64 * VEC) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                ss = fmaf(c[j + q], c[j + q], ss);
+                dot = fmaf(c[j + q], g[j + q], dot);
+            }
         }
         ss = wave_sum(ss);
         dot = wave_sum(dot);
@@ -146,16 +153,26 @@ __global__ __launch_bounds__(256) void layer_bwd_pre_kernel(const float *__restr
     }
     const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    for (int j = lane; j < d; j += 64) {
-        float t = g ? g[j] / den - c[j] * (ydot / den) : 0.f;
-        if (dC) t += dC[r * ldc + j];
-        if (drop_mask) {
-            t *= drop_mask[r * ldk + j];                      // the host-drawn noise tensor of the forward (0 or 1/(1-p))
-        } else if (drop_p > 0.f) {
-            const uint32_t h = mix32(seed ^ ((uint64_t)r_hash * 0x9E3779B97F4A7C15ULL + (uint64_t)j));
-            t = h < thr ? 0.f : t * keep_scale;
+    using V = typename VecT<VEC>::type;
+    for (int j = lane * VEC; j < d; j += 64 * VEC) {
+        float cv[VEC], gv[VEC], dc[VEC], mk[VEC], out[VEC];
+        *reinterpret_cast<V *>(cv) = *reinterpret_cast<const V *>(c + j);
+        if (g) *reinterpret_cast<V *>(gv) = *reinterpret_cast<const V *>(g + j);
+        if (dC) *reinterpret_cast<V *>(dc) = *reinterpret_cast<const V *>(dC + r * ldc + j);
+        if (drop_mask) *reinterpret_cast<V *>(mk) = *reinterpret_cast<const V *>(drop_mask + r * ldk + j);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float t = g ? gv[q] / den - cv[q] * (ydot / den) : 0.f;
+            if (dC) t += dc[q];
+            if (drop_mask) {
+                t *= mk[q];                                   // the host-drawn noise tensor of the forward (0 or 1/(1-p))
+            } else if (drop_p > 0.f) {
+                const uint32_t h = mix32(seed ^ ((uint64_t)r_hash * 0x9E3779B97F4A7C15ULL + (uint64_t)(j + q)));
+                t = h < thr ? 0.f : t * keep_scale;
+            }
+            out[q] = t * (cv[q] > 0.f ? 1.f : leaky);         // sign(C) == sign(M) wherever C was kept
         }
-        dM[r * ldm + j] = t * (c[j] > 0.f ? 1.f : leaky);     // sign(C) == sign(M) wherever C was kept
+        *reinterpret_cast<V *>(dM + r * ldm + j) = *reinterpret_cast<const V *>(out);
     }
 }
 
@@ -166,8 +183,13 @@ extern "C" int ngcf_layer_bwd_pre_f32(const float *dN, int64_t ldn, const float 
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows == 0) return NGCF_OK;
     if ((!dN && !dC) || !C || !dM || d <= 0) return fail(NGCF_ERR_ARG, "layer_bwd_pre: bad argument");
-    layer_bwd_pre_kernel<<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
-                                                                                 seed, drop_mask, ld_mask, row_ids, dM, ldm);
+    auto even = [](const float *p, int64_t ld) { return !p || (ld % 2 == 0 && ((uintptr_t)p & 7) == 0); };
+    if (d % 2 == 0 && even(dN, ldn) && even(dC, ldc) && even(C, ldC) && even(drop_mask, ld_mask) && even(dM, ldm))
+        layer_bwd_pre_kernel<2><<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
+                                                                                        seed, drop_mask, ld_mask, row_ids, dM, ldm);
+    else
+        layer_bwd_pre_kernel<1><<<dim3((unsigned)((n_rows + 3) / 4)), 256, 0, stream>>>(dN, ldn, dC, ldc, C, ldC, n_rows, d, leaky, drop_p,
+                                                                                        seed, drop_mask, ld_mask, row_ids, dM, ldm);
     LAUNCH_CHECK();
     return NGCF_OK;
 }
@@ -184,10 +206,29 @@ __global__ void add_rows_kernel(float *__restrict__ out, int64_t ldo, const floa
     }
 }
 
+// the same on 16-byte pieces (widths and leading dimensions that are multiples of 4, aligned rows: every padded matrix of the backward)
+__global__ void add_rows4_kernel(float *__restrict__ out, int64_t ldo, const float *__restrict__ add, int64_t lda, int64_t n_rows, int d4)
+{
+    const int64_t total = n_rows * d4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d4;
+        const int j = (int)(i - r * d4) * 4;
+        float4 a = *reinterpret_cast<const float4 *>(out + r * ldo + j);
+        const float4 b = *reinterpret_cast<const float4 *>(add + r * lda + j);
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        *reinterpret_cast<float4 *>(out + r * ldo + j) = a;
+    }
+}
+
 extern "C" int ngcf_add_rows_f32(float *out, int64_t ldo, const float *add, int64_t lda, int64_t n_rows, int d, void *stream_)
 {
     if (n_rows == 0) return NGCF_OK;
     if (!out || !add || d <= 0) return fail(NGCF_ERR_ARG, "add_rows: bad argument");
+    if (d % 4 == 0 && ldo % 4 == 0 && lda % 4 == 0 && aligned16(out) && aligned16(add)) {
+        add_rows4_kernel<<<grid_for(n_rows * (d / 4), 256), 256, 0, (hipStream_t)stream_>>>(out, ldo, add, lda, n_rows, d / 4);
+        LAUNCH_CHECK();
+        return NGCF_OK;
+    }
     add_rows_kernel<<<grid_for(n_rows * d, 256), 256, 0, (hipStream_t)stream_>>>(out, ldo, add, lda, n_rows, d);
     LAUNCH_CHECK();
     return NGCF_OK;
