@@ -372,10 +372,15 @@ def _gpu_worker(rank, world, port, mode, ret, backend="gloo", cabi=False, collec
             ok = ok and torch.equal(u2, u) and torch.equal(p2, p) and torch.equal(n2, n)
         u3, p3, _ = sh.gather(u_id[:7], pos[:9], torch.empty(0))   # another shape, no negatives (experiment.py:82-91)
         ok = ok and torch.equal(u3, u[:7]) and torch.equal(p3, p[:9])
+        big = [torch.cat([t, t.flip(0), t]) for t in (u_id, pos, neg)]      # a LARGER batch than any before: the gather exchange is rebuilt
+        ub_, pb_, nb_ = sh.gather(*big)
+        ok = ok and torch.equal(ub_[:64], u) and torch.equal(ub_[64:128], u.flip(0)) and torch.equal(pb_[128:], p) and torch.equal(nb_[:64], n)
+        u4, p4, n4 = sh.gather(u_id, pos, neg)
+        ok = ok and torch.equal(u4, u) and torch.equal(p4, p) and torch.equal(n4, n)
         if mode == "bipartite":
             # r04: nobody holds the previous result -> the same buffers are written again and E0 is not copied again; an in-place
             # update of a table (an optimizer step) is seen through its version counter
-            del au, ai, u2, p2, n2, u3, p3
+            del au, ai, u2, p2, n2, u3, p3, ub_, pb_, nb_, u4, p4, n4
             with torch.no_grad():
                 sh.propagate()
                 ptr = sh.allE_u.data_ptr()
