@@ -35,7 +35,9 @@ class _ReplayTrain(torch.autograd.Function):
         # the loss without a backward) and is dropped when the backward has run; `_TrainGraphs.outstanding()` reads it.
         ctx.token = _Token()
         runner.pending = weakref.ref(ctx.token)
-        return tuple(o.detach() for o in runner.outs)
+        fresh = [torch.empty_like(o) for o in runner.outs]             # fresh tensors like the eager path (the graph's own are overwritten
+        torch._foreach_copy_(fresh, [o.detach() for o in runner.outs])  # by the next replay): one multi-tensor copy
+        return tuple(fresh)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -45,11 +47,12 @@ class _ReplayTrain(torch.autograd.Function):
                                "overwritten (a second backward through the same forward, or a replay forced in between); set "
                                "model.auto_train_graph = False for such loops")
         ctx.token, r.pending = None, None
+        have = [(s, g) for s, g in zip(r.gouts, grads) if g is not None and g.data_ptr() != s.data_ptr()]
+        if have:
+            torch._foreach_copy_([s for s, _ in have], [g for _, g in have])      # the incoming gradients into the graph's inputs: one launch
         for s, g in zip(r.gouts, grads):
             if g is None:
                 s.zero_()
-            elif g.data_ptr() != s.data_ptr():
-                s.copy_(g)
         # The gradients leave as the graph's own buffers (no copies): with `zero_grad()` between two backward passes (the default
         # sets `.grad` to None) autograd adopts them and the next replay finds nobody holding them.  A `.grad` that still IS one
         # of these buffers - gradient accumulation over several backward calls, or `zero_grad(set_to_none=False)` - gets its own
@@ -588,7 +591,8 @@ class NGCF(nn.Module):
     def _graph_key(self, dev, sizes, year_idx):
         # the parameter tensors' addresses: from a cached list of the Parameter objects (walking the module tree costs 25 us, more
         # than the replay's launch) that is rebuilt after train() / eval(), .to() / .cuda(), load_state_dict() and every 16th call
-        if self._plist is None or self._graph_calls % 16 == 0:
+        self._key_calls = getattr(self, "_key_calls", 0) + 1           # (its own counter: `_graph_calls` only moves on inference replays)
+        if self._plist is None or self._key_calls % 16 == 0:
             self._plist = list(self.parameters())
         ptrs = tuple(p.data_ptr() for p in self._plist)
         return (sizes, year_idx, id(self.lap_list[year_idx]), str(dev), ptrs, float(self.emb_ratio))     # (emb_ratio is a kernel argument)
@@ -768,8 +772,7 @@ class NGCF(nn.Module):
             outs = g(*args)
         if self.check_indices and self._train_calls % max(1, int(self.index_check_every)) == 0:
             self.check_indices_now()
-        outs = [o.clone() for o in outs]                               # fresh tensors like the eager path (the graph's own are overwritten by the next replay)
-        return outs[0], outs[1], (outs[2] if has_neg else torch.empty(0))
+        return outs[0], outs[1], (outs[2] if has_neg else torch.empty(0))      # (fresh tensors: `_ReplayTrain.forward` copies them out)
 
     def forward(self, year, u_id, age, sex, month, day, dow, pos_item, neg_item, node_flag):
         dev = self._dev()
