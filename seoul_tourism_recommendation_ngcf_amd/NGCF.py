@@ -198,6 +198,11 @@ def _reference_bernoulli(n: int, p_drop: float, noise_shape=None):
     dropout, the noise tensor (0 or 1/(1-p) as torch rounds it) for the message dropout."""
     import ctypes as C
     keep = 1.0 - float(p_drop)
+    if keep >= 1.0 or keep <= 0.0:        # torch's dropout returns its input (p = 0) or zeros (p = 1) WITHOUT touching the generator
+        kept_all = keep >= 1.0
+        if noise_shape is not None:
+            return None, -1, torch.full(noise_shape, 1.0 if kept_all else 0.0, dtype=torch.float32)
+        return torch.full((n,), 1 if kept_all else 0, dtype=torch.uint8), n if kept_all else 0, None
     if _host_rng_ok():
         st = torch.get_rng_state()
         flags = None if noise_shape is not None else torch.empty(n, dtype=torch.uint8)

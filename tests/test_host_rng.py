@@ -56,6 +56,19 @@ def test_module_helper_consumes_the_default_generator_like_the_reference():
     assert torch.equal(torch.get_rng_state(), after)
 
 
+def test_degenerate_probabilities_do_not_touch_the_generator():
+    """`F.dropout` with p = 0 returns its input and with p = 1 zeros, both without a draw: so must the helper."""
+    torch.manual_seed(5)
+    before = torch.get_rng_state()
+    for p in (0.0, 1.0):
+        keep, n_kept, _ = ngcf_mod._reference_bernoulli(100, p)
+        _, _, noise = ngcf_mod._reference_bernoulli(6 * 7, p, (6, 7))
+        want = torch.nn.functional.dropout(torch.ones(100, dtype=torch.float64), p, True)
+        assert torch.equal(keep.bool(), want != 0) and n_kept == int((want != 0).sum())
+        assert torch.equal(noise, torch.nn.functional.dropout(torch.ones((6, 7)), p, True))
+    assert torch.equal(torch.get_rng_state(), before)
+
+
 def test_bad_state_is_refused():
     lib = _lib.load()
     st = torch.get_rng_state().clone()
