@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as _eng
-from .autograd import E0Cache, GatherTriple, propagate_with_grad
+from .autograd import E0Cache, GatherTriple, propagate_with_grad, static_result_counts
 
 
 class _ReplayTrain(torch.autograd.Function):
@@ -124,6 +124,8 @@ class _TrainGraphs:
         uw[self.idx[0].clamp(0, model.n_user - 1)] = rows_before
         self._keep = (self.ws.buf, model._scratch, model._status, getattr(model, "_seed_state", None))
         self._baked = self._pointers()
+        model._all_E = model.all_users_emb = model.all_items_emb = None     # (they alias the capture's all_E: set again by every replay)
+        self._free = static_result_counts(self.all_E)                       # ... which only this object and its autograd nodes hold now
 
     def _pointers(self):
         m = self.model
@@ -659,6 +661,8 @@ class NGCF(nn.Module):
                 self._graphs.pop(k, None)
             g = GraphedForward(self, sizes[0], year_idx, with_neg=sizes[2] > 0, pos_size=sizes[1], neg_size=sizes[2] or None)
         self._graphs[key] = g
+        if self._static_result_held(g.out[0], g._free):
+            return None                                                # a caller kept the last replay's all_*_emb: eager, into fresh tensors
         self._graph_calls += 1
         g.load_inputs(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item,
                       neg_item=neg_item if sizes[2] > 0 else None)
@@ -668,6 +672,16 @@ class NGCF(nn.Module):
         outs = [torch.empty_like(u), torch.empty_like(p)] + ([torch.empty_like(n)] if sizes[2] > 0 else [])
         torch._foreach_copy_(outs, [u, p] + ([n] if sizes[2] > 0 else []))         # fresh tensors like the eager path, one launch
         return outs[0], outs[1], (outs[2] if sizes[2] > 0 else torch.empty(0))
+
+    def _static_result_held(self, static_all_E, free_counts) -> bool:
+        """Does a caller still hold the previous replay's `all_users_emb` / `all_items_emb` / `_all_E` (or a view of them)?  They are
+        views of the graph's static all_E, which the next replay overwrites - the reference hands out a fresh `cat` per call
+        (NGCF.py:147-149), so a held tensor must stay what it was: then this forward runs eagerly (r04; r03 documented the
+        overwrite as a deviation).  The module's own references are dropped first - both paths set them again."""
+        d = self.__dict__
+        if d.get("_all_E") is static_all_E or getattr(d.get("all_users_emb"), "_base", None) is static_all_E:
+            d["_all_E"] = d["all_users_emb"] = d["all_items_emb"] = None
+        return static_result_counts(static_all_E) != free_counts
 
     def check_indices_now(self):
         """Raise IndexError if any graph-replayed forward since the last check saw an out-of-range id."""
@@ -741,9 +755,10 @@ class NGCF(nn.Module):
             if g is not None:
                 self._train_graphs[key] = g
             return None                                                # re-seeded since the last draw: this call draws eagerly (and re-seeds in place)
-        if g is not None and g.outstanding():
+        if g is not None and (g.outstanding() or self._static_result_held(g.all_E, g._free)):
             self._train_graphs[key] = g
-            return None                                                # an earlier replay still awaits its backward: this forward runs eagerly
+            return None                                                # an earlier replay still awaits its backward, or a caller kept its
+                                                                       # all_*_emb (views of the graph's static all_E): this forward runs eagerly
         if g is None:
             cur = torch.cuda.current_stream(dev).cuda_stream
             if key not in self._train_seen:

@@ -54,6 +54,14 @@ class _Probe:
     pass
 
 
+def static_result_counts(all_E: torch.Tensor):
+    """(Python references, C++ references, tensors on the storage) of a graph's STATIC all_E - compared with the same reading taken
+    when only the graph runner held it (`GraphedForward`, `NGCF._TrainGraphs`): anything more means a caller still holds the previous
+    replay's `model.all_items_emb` / `all_users_emb` / a slice of them, and the next forward must not replay over it (the reference
+    allocates a fresh all_E per call, NGCF.py:147-149)."""
+    return (sys.getrefcount(all_E), all_E._use_count(), torch._C._storage_Use_Count(all_E.untyped_storage()._cdata))
+
+
 class E0Cache:
     """The all_E of the previous inference forward, kept so that block 0 - E0 = cat(user table, item table), NGCF.py:120 - need not
     be copied again while the tables are unchanged (r04; SURVEY 2.2 K4: 563 MB through `copy_rows_kernel` per forward at C3, 0.21 ms).

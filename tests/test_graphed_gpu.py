@@ -163,6 +163,30 @@ def test_unchanged_callers_get_the_graph_replay(dev):
     plain.user_embedding.weight.data.copy_(auto.user_embedding.weight.data)
     plain.invalidate_all_E()       # r04: a write through .data from outside bypasses the version counter the retained all_E watches
     same(eval_batch())
+    # r04: a caller that KEEPS model.all_items_emb (demo.py:233 reads it) keeps what it read - the reference hands out a fresh all_E per
+    # call (NGCF.py:147-149).  Under replays the attribute is a view of the graph's static buffer: while somebody holds it (or a slice
+    # of it) the forward runs eagerly into fresh tensors; replays resume when it is released.
+    b1, b2, b3 = eval_batch(), eval_batch(), eval_batch()
+    same(b1)
+    same(b1)
+    calls = auto._graph_calls
+    held = auto.all_items_emb
+    kept = held.clone()
+    same(b2)                                                            # another batch: the injected rows (and so all_E) change
+    assert torch.equal(held, kept) and not torch.equal(auto.all_items_emb, kept) and auto._graph_calls == calls
+    piece = auto.all_users_emb[3:9]                                     # (an eager result now; hold a slice of it and release the first)
+    del held
+    same(b3)
+    del piece
+    same(b1)
+    same(b2)
+    assert auto._graph_calls > calls                                    # replaying again
+    held = auto.all_users_emb[:5]                                       # a SLICE of a replayed result
+    kept = held.clone()
+    calls = auto._graph_calls
+    same(b3)
+    assert torch.equal(held, kept) and auto._graph_calls == calls
+    del held
 
 
 def test_graphed_train_step_replays_the_eager_step(dev):

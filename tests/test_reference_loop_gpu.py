@@ -317,6 +317,21 @@ def test_two_forwards_before_one_backward_do_not_share_saved_activations(lap, de
     calls = m._train_calls
     grad_of(m, b1)
     assert m._train_calls == calls + 1                                  # replayed again
+    # a caller that keeps all_items_emb of a replayed training forward keeps it intact: the next forward of the shape runs eagerly
+    crit(*m(node_flag=False, **b1)).backward()
+    calls = m._train_calls
+    held = m.all_items_emb
+    kept = held.clone()
+    with torch.no_grad():
+        m.item_embedding.weight.mul_(1.25)                              # (so that the next forward's all_E differs)
+        ref.item_embedding.weight.mul_(1.25)
+    m.zero_grad()
+    crit(*m(node_flag=False, **b2)).backward()
+    assert torch.equal(held, kept) and not torch.equal(m.all_items_emb, kept) and m._train_calls == calls
+    del held
+    m.zero_grad()
+    crit(*m(node_flag=False, **b2)).backward()
+    assert m._train_calls == calls + 1
     # the attributes alias the forward that just ran (a replay), not whichever capture ran last
     with torch.no_grad():
         want_items = ref(node_flag=False, **b1) and ref.all_items_emb.clone()
