@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as _eng
-from .autograd import E0Cache, GatherTriple, propagate_with_grad, static_result_counts
+from .autograd import E0Cache, GatherTriple, propagate_with_grad, static_result_baseline, static_result_counts
 
 
 class _ReplayTrain(torch.autograd.Function):
@@ -125,7 +125,7 @@ class _TrainGraphs:
         self._keep = (self.ws.buf, model._scratch, model._status, getattr(model, "_seed_state", None))
         self._baked = self._pointers()
         model._all_E = model.all_users_emb = model.all_items_emb = None     # (they alias the capture's all_E: set again by every replay)
-        self._free = static_result_counts(self.all_E)                       # ... which only this object and its autograd nodes hold now
+        self._free = static_result_baseline(self.all_E)                      # ... which only this object and its autograd nodes hold now
 
     def _pointers(self):
         m = self.model

@@ -62,6 +62,13 @@ def static_result_counts(all_E: torch.Tensor):
     return (sys.getrefcount(all_E), all_E._use_count(), torch._C._storage_Use_Count(all_E.untyped_storage()._cdata))
 
 
+def static_result_baseline(all_E: torch.Tensor):
+    """The reading of `static_result_counts` for a tensor only its runner holds, taken through ONE intermediate frame - the shape of
+    the later check (`NGCF._static_result_held(all_E, ...)` -> `static_result_counts(all_E)`): every frame that binds the tensor to a
+    parameter is one more Python reference, so the two readings must come up the same call depth."""
+    return static_result_counts(all_E)
+
+
 class E0Cache:
     """The all_E of the previous inference forward, kept so that block 0 - E0 = cat(user table, item table), NGCF.py:120 - need not
     be copied again while the tables are unchanged (r04; SURVEY 2.2 K4: 563 MB through `copy_rows_kernel` per forward at C3, 0.21 ms).

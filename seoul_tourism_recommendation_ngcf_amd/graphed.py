@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from . import engine as _eng
-from .autograd import propagate_forward, static_result_counts
+from .autograd import propagate_forward, static_result_baseline
 
 
 class _Buffers:
@@ -77,7 +77,7 @@ class GraphedForward:
         model.user_embedding.weight.data[:1].copy_(saved)  # row 0 was injected with the all-zero warm-up batch
         self.status.zero_()
         self._baked = self._baked_pointers()
-        self._free = static_result_counts(self.out[0])     # what the static all_E reads when nobody but this object holds it
+        self._free = static_result_baseline(self.out[0])     # what the static all_E reads when nobody but this object holds it
 
     def _body(self):
         m, i = self.model, self.inputs
