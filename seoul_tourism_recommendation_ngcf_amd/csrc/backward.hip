@@ -1038,6 +1038,300 @@ __global__ __launch_bounds__(256) void spmm_t_rows_kernel(const int64_t *__restr
         if (lane + 64 * q < d) dst[lane + 64 * q] = acc[q];
 }
 
+
+// ---- r04: the same sums, 16 rows to a wave, the MEMBERSHIP test out of LDS, loads and stores kept apart -----------------------
+// The kernel above is bound by LATENCY, not by bytes (C3: 0.93 ms for 0.4 GB of indices in and 0.56 GB of rows out): a wave owns
+// one row and runs rowptr -> colidx -> slot -> X -> store as a chain of dependent round trips, one 64-entry load in flight, 1.1 M
+// times.  What r04 measured on the way here (tools/t_rows_lab.py, per-wave clocks):
+//   * moving only the slot test into LDS: 0.93 -> 0.96 ms - the chain was the cost, not the gather;
+//   * 16 / 32 rows to a wave with the hits applied as they are found: 0.80 - 0.98 ms, of which 0.57 - 0.64 ms in the row WRITES:
+//     on gfx9 one counter (vmcnt) covers loads and stores and retires in order, so every load that follows a store waits for that
+//     store's acknowledge (~2 us under load) - a store per row and a load per hit made a chain again, and a load that MAY happen in
+//     a block (`hit ? init[..] : 0`) makes the compiler wait for everything at the join even when it did not happen.
+// So: a wave takes 16 CONSECUTIVE rows - one contiguous stretch of colidx, scanned 512 entries at a time with eight independent
+// loads in flight; whether column c is one of the R rows is ONE BIT of a bitmap (N / 8 bytes: 137 KB at C3) that a persistent
+// workgroup (16 waves, one per CU) holds in LDS, so the 99 % of entries that miss cost an LDS read; the hits (entry, column, slot,
+// value) are parked, in entry order, in a small per-wave list in LDS while the scan goes on (loads only), and the list is drained
+// eight hits at a time: eight X rows loaded together, then applied in order to ONE running accumulator that is written when the
+// row changes - the row an entry belongs to is a ballot over the 17 row pointers held in lanes - with the rows between two hits
+// written as init / zero from a loop that loads nothing.  Units are handed out through counters (two levels, see the kernel), the
+// long (item) rows at the end of the range first.  Per row the same entries are added in
+// the same order with the same fmaf: bit-identical to the kernel above.
+__global__ void slot_bitmap_kernel(const int32_t *__restrict__ slot, int64_t n, uint32_t *__restrict__ bm, int64_t n_words,
+                                   unsigned long long *__restrict__ counters, int n_counters)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_counters) counters[i] = 0ull;
+    const unsigned long long b = __ballot(i < n && slot[i] >= 0);
+    if ((threadIdx.x & 63) == 0) {
+        const int64_t w = i >> 5;
+        if (w < n_words) bm[w] = (uint32_t)b;
+        if (w + 1 < n_words) bm[w + 1] = (uint32_t)(b >> 32);
+    }
+}
+
+static constexpr int kTrWaves = 16, kTrWGs = 256, kTrRows = 16, kTrU = 8, kTrPanels = 8;
+static constexpr int kTrList = 84;                 // parked hits per wave (16 bytes each: 1 344 B a wave, 21 KB a workgroup)
+static constexpr int kTrGroup = 8;                 // hits whose X rows are loaded together
+static constexpr int kTrChunk = 32;                // units a workgroup takes from the device-wide counter at a time
+static constexpr int64_t kTrLdsBytes = 160 * 1024;
+
+// one row (or one segment of a cut row), 64 entries at a time: the walk of spmm_t_rows_kernel with the bitmap in front of the slot table
+template <int NQ>
+__device__ __forceinline__ void t_rows_walk(const uint32_t *bm, const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                            int64_t begin, int64_t end, int64_t row, bool first, const int32_t *__restrict__ slot,
+                                            const float *__restrict__ X, int64_t ldx, int d, const float *__restrict__ init, int64_t ldi,
+                                            float *__restrict__ dst, const EdgeDropR &dr, int lane)
+{
+    float acc[NQ];
+    const int s_self = first && init && ((bm[row >> 5] >> (row & 31)) & 1u) ? slot[row] : -1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = (s_self >= 0 && lane + 64 * q < d) ? init[(int64_t)s_self * ldi + lane + 64 * q] : 0.f;
+    for (int64_t base = begin; base < end; base += 64) {
+        const int cnt = (int)(end - base < 64 ? end - base : 64);
+        int sl = -1;
+        float v = 0.f;
+        if (lane < cnt) {
+            const int c = colidx[base + lane];
+            if ((bm[c >> 5] >> (c & 31)) & 1u) {
+                sl = slot[c];
+                v = vals[base + lane];
+                if (dr.n > 0 && !edge_keep(dr, row, c)) sl = -1;
+            }
+        }
+        unsigned long long hits = __ballot(sl >= 0);
+        while (hits) {                                         // wave-uniform: hits in entry order
+            const int j = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const int sj = __shfl(sl, j);
+            const float vj = __shfl(v, j);
+            const float *x = X + (int64_t)sj * ldx;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (lane + 64 * q < d) acc[q] = fmaf(vj, x[lane + 64 * q], acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < d) dst[lane + 64 * q] = acc[q];
+}
+
+template <int NQ>
+__global__ __launch_bounds__(kTrWaves * 64) void spmm_t_rows_bm_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                                    const float *__restrict__ vals, int64_t n_rows,
+                                                                    const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
+                                                                    int64_t n_seg, int seg_len, const int32_t *__restrict__ slot,
+                                                                    const uint32_t *__restrict__ bm_g, int n_words,
+                                                                    unsigned long long *__restrict__ counter,
+                                                                    const float *__restrict__ X, int64_t ldx, int d,
+                                                                    const float *__restrict__ init, int64_t ldi, float *__restrict__ out,
+                                                                    int64_t ldo, float *__restrict__ partial, int dp, EdgeDrop dr_in)
+{
+    extern __shared__ uint32_t bm[];                            // [n_words bitmap][kTrWaves lists of kTrList int4]
+    {                                                          // the bitmap: 16 bytes a lane, four loads in flight
+        const uint4 *src = reinterpret_cast<const uint4 *>(bm_g);
+        uint4 *dst4 = reinterpret_cast<uint4 *>(bm);
+        const int n4 = n_words / 4;                             // (n_words is a multiple of 4)
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * kTrWaves * 64) {
+            uint4 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = i0 + k * kTrWaves * 64 < n4 ? src[i0 + k * kTrWaves * 64] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k * kTrWaves * 64 < n4) dst4[i0 + k * kTrWaves * 64] = r[k];
+        }
+        if (threadIdx.x == 0)                                   // the unit pool of this workgroup: "chunk used up" (see below)
+            *reinterpret_cast<unsigned long long *>(reinterpret_cast<int4 *>(bm + n_words) + kTrWaves * kTrList) = (unsigned long long)kTrChunk;
+    }
+    __syncthreads();
+    const EdgeDropR dr = resolve_drop(dr_in);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int4 *list = reinterpret_cast<int4 *>(bm + n_words) + wave * kTrList;       // this wave's parked hits: (entry - begin, column, slot, value)
+    // the segments of the cut rows (a few thousand at most): one wave each, into the partial sums
+    for (int64_t s = (int64_t)blockIdx.x * kTrWaves + wave; s < n_seg; s += (int64_t)gridDim.x * kTrWaves) {
+        const int64_t begin = seg_begin[s], row = seg_row[s], row_end = rowptr[row + 1];
+        t_rows_walk<NQ>(bm, colidx, vals, begin, begin + seg_len < row_end ? begin + seg_len : row_end, row, begin == rowptr[row], slot, X, ldx, d,
+                        init, ldi, partial + s * (int64_t)dp, dr, lane);
+    }
+    const int64_t n_units = (n_rows + kTrRows - 1) / kTrRows;
+    // Units are handed out in two levels.  A ticket per unit from ONE device-wide counter was the whole cost of an earlier version:
+    // returning atomics on one address retire at ~13 ns each (69 000 units: 0.9 ms), and as vector-memory operations they hold up,
+    // in order, every load issued behind them.  So the device-wide counter hands out chunks of kTrChunk units to a workgroup
+    // (4 300 atomics at C3) and the waves of the workgroup draw from the chunk with an LDS atomic: `pool` = (chunk base << 24 | units
+    // drawn); the wave that draws number kTrChunk exactly is the one that fetches the next chunk, later ones wait for it.
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(reinterpret_cast<int4 *>(bm + n_words) + kTrWaves * kTrList);
+    for (;;) {
+        unsigned long long t = 0;
+        if (lane == 0) {
+            for (;;) {
+                const unsigned long long old = atomicAdd(pool, 1ull);
+                const unsigned long long drawn = old & 0xffffffull;
+                if (drawn < (unsigned long long)kTrChunk) {
+                    t = (old >> 24) + drawn;
+                    break;
+                }
+                if (drawn == (unsigned long long)kTrChunk) {                      // this wave fetches the next chunk and takes its first unit
+                    t = atomicAdd(counter, (unsigned long long)kTrChunk);
+                    __hip_atomic_store(pool, (t << 24) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                while ((__hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffffull) > (unsigned long long)kTrChunk)
+                    __builtin_amdgcn_s_sleep(8);                                   // a chunk is on its way (microseconds)
+            }
+        }
+        t = __shfl(t, 0);
+        if (t >= (unsigned long long)n_units) break;           // every wave gets here: the counters only grow
+        const int64_t row0 = (n_units - 1 - (int64_t)t) * kTrRows;
+        const int nr = (int)(n_rows - row0 < kTrRows ? n_rows - row0 : kTrRows);
+        const long long rp = rowptr[row0 + (lane < nr ? lane : nr)];          // lanes 0 .. nr: the row pointers; the rest repeat the last
+        const long long rp_next = __shfl_down(rp, 1);
+        // rows longer than seg_len are cut: their sums come from the segments above and the fix-up, their entries are skipped here
+        unsigned long long live = __ballot(lane < nr && rp_next - rp <= seg_len);
+        int self = -1;                                         // lane k: the row of `init` that output row row0 + k starts from
+        if (init && lane < nr && ((bm[(row0 + lane) >> 5] >> ((row0 + lane) & 31)) & 1u)) self = slot[row0 + lane];
+        while (live) {                                         // maximal runs [ka, kb) of rows that are not cut: one contiguous stretch of entries
+            const int ka = __builtin_ctzll(live);
+            const int kb = ka + __builtin_ctzll(~(live >> ka));  // (bits 16 .. 63 of live are clear)
+            live &= ~0ull << kb;
+            const int64_t begin = __shfl(rp, ka), end = __shfl(rp, kb);
+            int cur = ka;                                      // the row the accumulator belongs to
+            float acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+            // the accumulator of row r starts from its init row.  The load happens in a block of its own and is SETTLED there (an
+            // asm that reads the value, so the wait for it is placed inside the block): otherwise the compiler waits, at the join,
+            // for a load that mostly did not happen - and on gfx9 that wait (vmcnt(0)) is also a wait for every store before it
+            auto start_row = [&](int r) {
+                const int sr = __shfl(self, r);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+                if (sr >= 0) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (lane + 64 * q < d) acc[q] = init[(int64_t)sr * ldi + lane + 64 * q];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) asm volatile("v_mov_b32 %0, %0" : "+v"(acc[q]));
+                }
+            };
+            // write row `cur`, then the rows up to (not including) `upto`, which have no hit: zeros (a loop of stores and nothing
+            // else - merged with the init rows the compiler shares the store and waits before it) and, rarely, their init row
+            auto advance = [&](int upto) {
+                float *dst = out + (row0 + cur) * ldo;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if (lane + 64 * q < d) dst[lane + 64 * q] = acc[q];
+                unsigned long long with_init = __ballot(self >= 0) & (upto >= 64 ? ~0ull : (1ull << upto) - 1ull) & (~0ull << (cur + 1));
+                for (int r = cur + 1; r < upto; ++r) {
+                    if ((with_init >> r) & 1ull) continue;
+                    dst = out + (row0 + r) * ldo;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (lane + 64 * q < d) dst[lane + 64 * q] = 0.f;
+                }
+                while (with_init) {
+                    const int r = __builtin_ctzll(with_init);
+                    with_init &= with_init - 1;
+                    const int sr = __shfl(self, r);
+                    dst = out + (row0 + r) * ldo;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (lane + 64 * q < d) dst[lane + 64 * q] = init[(int64_t)sr * ldi + lane + 64 * q];
+                }
+            };
+            // one hit, its X row in x[]: close the rows before it, add it
+            auto apply = [&](int e_rel, int c, float vj, const float (&x)[NQ]) {
+                const long long e = begin + e_rel;
+                const int rj = __popcll(__ballot(lane >= 1 && lane <= nr && rp <= e));   // rows that begin at or before e, minus one
+                if (dr.n > 0 && !edge_keep(dr, row0 + rj, c)) return;
+                if (rj != cur) {
+                    advance(rj);
+                    cur = rj;
+                    start_row(rj);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = fmaf(vj, x[q], acc[q]);
+            };
+            start_row(ka);
+            int n_list = 0;
+            for (int64_t base = begin;; base += 64 * kTrU) {
+                const bool more = base < end;
+                int c[kTrU], sl[kTrU];
+                float v[kTrU];
+                unsigned long long hm[kTrU];
+                int n_new = 0;
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < kTrU; ++u) {
+                        const int64_t e = base + 64 * u + lane;
+                        c[u] = e < end ? colidx[e] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kTrU; ++u) {
+                        sl[u] = -1;
+                        v[u] = 0.f;
+                        if (c[u] >= 0 && ((bm[c[u] >> 5] >> (c[u] & 31)) & 1u)) {
+                            sl[u] = slot[c[u]];
+                            v[u] = vals[base + 64 * u + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kTrU; ++u) {
+                        hm[u] = __ballot(sl[u] >= 0);
+                        n_new += __popcll(hm[u]);
+                    }
+                }
+                if (n_list > 0 && (!more || n_list + n_new > kTrList)) {          // drain the list: eight X rows at a time
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < n_list; i += kTrGroup) {
+                        int4 ent[kTrGroup];
+                        float x[kTrGroup][NQ];
+#pragma unroll
+                        for (int g = 0; g < kTrGroup; ++g) {
+                            ent[g] = list[i + g < n_list ? i + g : i];
+                            const float *xr = X + (int64_t)__builtin_amdgcn_readfirstlane(ent[g].z) * ldx;
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) x[g][q] = lane + 64 * q < d ? xr[lane + 64 * q] : 0.f;
+                        }
+#pragma unroll
+                        for (int g = 0; g < kTrGroup; ++g)
+                            if (i + g < n_list)
+                                apply(__builtin_amdgcn_readfirstlane(ent[g].x), __builtin_amdgcn_readfirstlane(ent[g].y),
+                                      __int_as_float(__builtin_amdgcn_readfirstlane(ent[g].w)), x[g]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    n_list = 0;
+                }
+                if (!more) break;
+                if (n_new > kTrList) {                          // more hits in one window than the list holds (a dense X): one by one
+#pragma unroll
+                    for (int u = 0; u < kTrU; ++u) {
+                        unsigned long long hits = hm[u];
+                        while (hits) {
+                            const int j = __builtin_ctzll(hits);
+                            hits &= hits - 1;
+                            const float *xr = X + (int64_t)__shfl(sl[u], j) * ldx;
+                            float x[NQ];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) x[q] = lane + 64 * q < d ? xr[lane + 64 * q] : 0.f;
+                            apply((int)(base - begin) + 64 * u + j, __shfl(c[u], j), __shfl(v[u], j), x);
+                        }
+                    }
+                } else if (n_new > 0) {                         // park them behind the ones already there, in entry order
+#pragma unroll
+                    for (int u = 0; u < kTrU; ++u) {
+                        if (sl[u] >= 0) {
+                            const int pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm[u], 0));
+                            list[pos] = make_int4((int)(base - begin) + 64 * u + lane, c[u], sl[u], __float_as_int(v[u]));
+                        }
+                        n_list += __popcll(hm[u]);
+                    }
+                }
+            }
+            advance(kb);
+        }
+    }
+}
+
 extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, const float *X, int64_t ldx, int d, const float *init,
                                     int64_t ldi, float *out, int64_t ldo, float drop_p, const uint64_t *seeds, int n_seeds,
                                     void *workspace, int64_t workspace_bytes, void *stream_)
@@ -1052,6 +1346,20 @@ extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, co
     for (int q = 0; q < n_seeds; ++q) dr.seed[q] = seeds[q];
     const int64_t seg_blocks = (c->n_seg + 3) / 4, row_blocks = (c->n_rows + 3) / 4;
     if (seg_blocks + row_blocks >= (int64_t)1 << 31) return fail(NGCF_ERR_ARG, "spmm_t_rows: too many rows for one launch");
+    // r04: the membership bitmap of the R rows in LDS (see spmm_t_rows_bm_kernel) where it fits (N / 8 bytes + 21 KB of hit lists <= 160 KB: N <= 1.13 M) and the matrix
+    // is large enough for a persistent grid to pay; it lives behind the partial sums in the workspace
+    const int64_t n_slot = std::max(c->n_cols, c->n_rows);      // (square in every use: the slot table covers rows and columns)
+    const int64_t n_words = (n_slot + 127) / 128 * 4;             // 32-bit words, a multiple of 4
+    const int64_t part_bytes = c->n_seg > 0 ? align_up(c->n_seg * align_up(std::min(d, 512), 4) * (int64_t)sizeof(float), 256) + 256 : 256;
+    uint32_t *bitmap = nullptr;
+    unsigned long long *counters = nullptr;
+    if (ngcf_opts().t_rows_bitmap && c->n_rows == c->n_cols && n_words * 4 + kTrWaves * kTrList * 16 + 16 <= kTrLdsBytes && c->nnz >= (1 << 22) && workspace &&
+        d <= 512 * kTrPanels && workspace_bytes >= part_bytes + n_words * 4 + 1024) {
+        bitmap = reinterpret_cast<uint32_t *>(align_up((int64_t)(uintptr_t)workspace + part_bytes, 256));
+        counters = reinterpret_cast<unsigned long long *>(align_up((int64_t)(uintptr_t)(bitmap + n_words), 256));   // one per panel
+        slot_bitmap_kernel<<<(unsigned)((n_slot + 255) / 256), 256, 0, stream>>>(slot, n_slot, bitmap, n_words, counters, kTrPanels);
+        LAUNCH_CHECK();
+    }
     for (int col0 = 0; col0 < d; col0 += 512) {                 // panels of 512 columns (a lane holds 8)
         const int w = std::min(512, d - col0);
         const int dp = (int)align_up(w, 4);
@@ -1061,6 +1369,33 @@ extern "C" int ngcf_spmm_t_rows_f32(const ngcf_csr_t *c, const int32_t *slot, co
             if (!workspace || workspace_bytes < need)
                 return fail(NGCF_ERR_WORKSPACE, "spmm_t_rows: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
             partial = reinterpret_cast<float *>(align_up((int64_t)(uintptr_t)workspace, 256));
+        }
+        if (bitmap) {
+#define NGCF_TROWS_BM(NQ)                                                                                                             \
+    do {                                                                                                                              \
+        static bool attr_set[kMaxDevices] = {};                                                                                       \
+        const int dev_i = current_device_slot();                                                                                      \
+        if (!attr_set[dev_i]) {                                                                                                       \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_t_rows_bm_kernel<NQ>),                                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrLdsBytes));                                     \
+            attr_set[dev_i] = true;                                                                                                   \
+        }                                                                                                                             \
+        spmm_t_rows_bm_kernel<NQ><<<dim3(kTrWGs), kTrWaves * 64, (size_t)n_words * 4 + kTrWaves * kTrList * 16 + 16, stream>>>(                                       \
+            c->rowptr, c->colidx, c->vals, c->n_rows, c->seg_row, c->seg_begin, c->n_seg, c->seg_len, slot, bitmap, (int)n_words,     \
+            counters + col0 / 512, X + col0, ldx, w, init ? init + col0 : nullptr, ldi, out + col0, ldo, partial, dp, dr);                                   \
+    } while (0)
+            if (w <= 64) NGCF_TROWS_BM(1);
+            else if (w <= 128) NGCF_TROWS_BM(2);
+            else if (w <= 256) NGCF_TROWS_BM(4);
+            else NGCF_TROWS_BM(8);
+#undef NGCF_TROWS_BM
+            LAUNCH_CHECK();
+            if (c->n_heavy > 0) {
+                spmm_fixup_kernel<1><<<dim3((unsigned)((c->n_heavy + 3) / 4)), 256, 0, stream>>>(c->heavy_row, c->heavy_seg_ptr, c->n_heavy,
+                                                                                              partial, dp, w, out + col0, ldo);
+                LAUNCH_CHECK();
+            }
+            continue;
         }
 #define NGCF_TROWS(NQ)                                                                                                                \
     spmm_t_rows_kernel<NQ><<<dim3((unsigned)(seg_blocks + row_blocks)), 256, 0, stream>>>(                                            \

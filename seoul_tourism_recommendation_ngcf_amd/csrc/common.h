@@ -69,6 +69,7 @@ struct NgcfOptions {
     int dense_tall = 1;            // NGCF_DENSE_TALL: 256 / 512 output columns as 96-row x 128-column workgroups: 0 never, 1 where measured faster, 2 always
     int dense_il_lab = 0;          // NGCF_DENSE_IL_LAB (LAB): the interleaved kernel taken apart: 1 no stores, 2 no loads, 3 neither
     // backward.hip
+    int t_rows_bitmap = 1;         // NGCF_T_ROWS_BITMAP: 0 keeps the row-sparse transposed product on the slot-table kernel at every size
     int bwd_input_resident = 1;    // NGCF_BWD_INPUT_RESIDENT: 0 keeps the staged input-gradient kernel at every size
     // csr.hip
     int slice_max_mb = 48;         // NGCF_SLICE_MAX_MB: largest table slice a d-sliced group may gather from

@@ -41,6 +41,7 @@ const OptField kOptFields[] = {
     {"dense_il_lab", &NgcfOptions::dense_il_lab, nullptr},
     {"dense_tall", &NgcfOptions::dense_tall, nullptr},
     {"bwd_input_resident", &NgcfOptions::bwd_input_resident, nullptr},
+    {"t_rows_bitmap", &NgcfOptions::t_rows_bitmap, nullptr},
     {"slice_max_mb", &NgcfOptions::slice_max_mb, nullptr},
     {"swept_lpe", &NgcfOptions::swept_lpe, nullptr},
     {"swept_waves", &NgcfOptions::swept_waves, nullptr},

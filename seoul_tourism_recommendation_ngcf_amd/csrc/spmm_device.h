@@ -140,7 +140,14 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     float *dst = out + (int64_t)heavy_row[h] * ldo;
     for (int o = lane * VEC; o < d; o += 64 * VEC) {
         V acc = vzero<VEC>();
-        for (int64_t s = s0; s < s1; ++s) acc = vadd(acc, *reinterpret_cast<const V *>(partial + s * (int64_t)dp + o));
+        for (int64_t s = s0; s < s1; s += 8) {                  // eight partial sums in flight, added in segment order
+            V t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const V *>(partial + (s + k < s1 ? s + k : s) * (int64_t)dp + o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s + k < s1) acc = vadd(acc, t[k]);
+        }
         *reinterpret_cast<V *>(dst + o) = acc;
     }
 }

@@ -357,6 +357,40 @@ def test_row_sparse_transposed_product_vs_dense(d, heavy, drop, dev):
     assert float((again - want).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("d,n_item,drop", [(128, 20000, 0.0), (130, 600, 0.3), (65, 20000, 0.3)])
+def test_row_sparse_transposed_product_with_the_bitmap_in_lds_is_bit_identical(d, n_item, drop, dev, lib_options):
+    """r04: on a large matrix (>= 2^22 stored entries, N <= 1.13 M) `ngcf_spmm_t_rows_f32` runs `spmm_t_rows_bm_kernel`: 16 consecutive
+    rows per wave, the membership of an entry's column in the R rows tested on a bitmap in LDS, hits parked and replayed in entry
+    order, units drawn from a two-level counter.  Per row the same entries in the same order with the same fmaf: the results must be
+    the one-wave-per-row slot-table kernel's bit for bit (cut rows inside a unit: 600 items; a ragged last unit: 200 600 rows;
+    device-side edge dropout; with and without the direct part; rows 0..2 and the last 70 among the R rows)."""
+    pkg = _pkg()
+    eng = pkg.engine
+    coo = pkg.graphs.synthetic_bipartite(200_000, n_item, 2_300_000, seed=17, device=dev)
+    N = coo["n_user"] + coo["n_item"]
+    order = torch.sort(coo["cols"], stable=True).indices
+    Lt = eng.LaplacianCSR.from_coo(coo["cols"][order], coo["rows"][order], coo["vals"][order], N, N)
+    assert Lt.nnz >= 1 << 22 and (Lt.n_segments > 0 or n_item != 600)
+    g = torch.Generator().manual_seed(d)
+    rows = torch.unique(torch.cat([torch.randint(0, N, (3000,), generator=g), torch.arange(N - 70, N), torch.arange(0, 3)])).to(dev)
+    R = rows.numel()
+    X, init = (torch.randn((R, d), generator=g).to(dev) for _ in range(2))
+    slot = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    slot[rows] = torch.arange(R, dtype=torch.int32, device=dev)
+    ed = ([11, 12], drop) if drop else None
+    ws = eng.Workspace()
+    outs = []
+    for bitmap in (0, 1):
+        lib_options(t_rows_bitmap=bitmap)
+        a = torch.full((N, d + 3), 7.0, device=dev)[:, :d]
+        b = torch.full((N, d), 7.0, device=dev)
+        eng.spmm_t_rows(Lt, slot, X, init, a, ws, ed)
+        eng.spmm_t_rows(Lt, slot, X, None, b, ws, ed)
+        outs.append((a.clone(), b.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][0].abs().max()) > 0 and bool((outs[1][0][rows] - outs[1][1][rows] - init).abs().max() < 1e-4)
+
+
 @pytest.mark.parametrize("node_mode,dense_grad", [(None, True), ("reference", True), ("device", True), (None, False), ("device", False)])
 def test_training_gradients_are_bit_identical_from_run_to_run(node_mode, dense_grad, dev, monkeypatch):
     """Two training steps from the same seed on the same batch (duplicate users and items in it) give bit-identical gradients of
