@@ -41,9 +41,61 @@ __global__ __launch_bounds__(256) void bpr_backward_kernel(const float *__restri
         const float gu = g * (s * (sp * b - sn * c) + ((Bu == 1 && r > 0) ? 0.f : two_wd * a));
         const float gp = g * (s * sp * a + ((Bp == 1 && r > 0) ? 0.f : two_wd * b));
         const float gn = g * (-s * sn * a + ((Bn == 1 && r > 0) ? 0.f : two_wd * c));
-        if (Bu == R) du[ru * D + j] = gu; else atomicAdd(&du[j], gu);
-        if (Bp == R) dp[rp * D + j] = gp; else atomicAdd(&dp[j], gp);
-        if (Bn == R) dn[rn * D + j] = gn; else atomicAdd(&dn[j], gn);
+        if (Bu == R) du[ru * D + j] = gu;          // a broadcast operand's gradient is a sum over the rows: bpr_backward_bcast_kernel
+        if (Bp == R) dp[rp * D + j] = gp;
+        if (Bn == R) dn[rn * D + j] = gn;
+    }
+}
+
+// The gradient of a BROADCAST operand (a [1, D] row against R > 1 rows: bprloss.py broadcasts like torch): the sum of the per-row
+// terms in ROW ORDER, by one workgroup - the per-row coefficients of 256 rows at a time into LDS (a wave per row), then a thread
+// per column adds them up.  (r04: this was three float atomicAdds per element - the last ones in the library; a rare path, R * D
+// multiply-adds on one CU.)
+__global__ __launch_bounds__(256) void bpr_backward_bcast_kernel(const float *__restrict__ u, int64_t Bu, const float *__restrict__ p,
+                                                                 int64_t Bp, const float *__restrict__ n, int64_t Bn, int64_t R, int D,
+                                                                 float wd, float batch_size, const float *__restrict__ gout,
+                                                                 float *__restrict__ du, float *__restrict__ dp, float *__restrict__ dn)
+{
+    __shared__ float c_pos[256], c_neg[256];                   // s * sign(u.p), s * sign(u.n) of the rows of a chunk
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float g = gout[0] / batch_size, two_wd = 2.f * wd;
+    for (int j0 = 0; j0 < D; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        float au = 0.f, ap = 0.f, an = 0.f;
+        for (int64_t r0 = 0; r0 < R; r0 += 256) {
+            const int cnt = (int)(R - r0 < 256 ? R - r0 : 256);
+            __syncthreads();
+            for (int rr = wave; rr < cnt; rr += 4) {
+                const int64_t r = r0 + rr;
+                const float *ur = u + (Bu == 1 ? 0 : r) * D, *pr = p + (Bp == 1 ? 0 : r) * D, *nr = n + (Bn == 1 ? 0 : r) * D;
+                float up = 0.f, un = 0.f;
+                for (int k = lane; k < D; k += 64) {
+                    up = fmaf(ur[k], pr[k], up);
+                    un = fmaf(ur[k], nr[k], un);
+                }
+                up = wave_sum(up);
+                un = wave_sum(un);
+                const float sg = -1.f / (1.f + expf(fabsf(up) - fabsf(un)));
+                if (lane == 0) {
+                    c_pos[rr] = sg * (up > 0.f ? 1.f : (up < 0.f ? -1.f : 0.f));
+                    c_neg[rr] = sg * (un > 0.f ? 1.f : (un < 0.f ? -1.f : 0.f));
+                }
+            }
+            __syncthreads();
+            if (j < D)
+                for (int rr = 0; rr < cnt; ++rr) {
+                    const int64_t r = r0 + rr;
+                    const float a = u[(Bu == 1 ? 0 : r) * D + j], b = p[(Bp == 1 ? 0 : r) * D + j], c = n[(Bn == 1 ? 0 : r) * D + j];
+                    au += c_pos[rr] * b - c_neg[rr] * c;
+                    ap = fmaf(c_pos[rr], a, ap);
+                    an = fmaf(-c_neg[rr], a, an);
+                }
+        }
+        if (j < D) {                                           // the weight-decay term of a broadcast row is counted once
+            if (Bu == 1) du[j] = g * (au + two_wd * u[j]);
+            if (Bp == 1) dp[j] = g * (ap + two_wd * p[j]);
+            if (Bn == 1) dn[j] = g * (an + two_wd * n[j]);
+        }
     }
 }
 
@@ -56,12 +108,13 @@ extern "C" int ngcf_bpr_backward_f32(const float *u, int64_t Bu, const float *p,
     const int64_t R = std::max(Bu, std::max(Bp, Bn));
     if (R < 1 || (Bu != 1 && Bu != R) || (Bp != 1 && Bp != R) || (Bn != 1 && Bn != R))
         return fail(NGCF_ERR_ARG, "bpr_backward: row counts %lld/%lld/%lld do not broadcast", (long long)Bu, (long long)Bp, (long long)Bn);
-    if (Bu != R) HIP_TRY(hipMemsetAsync(du, 0, sizeof(float) * (size_t)D, stream));
-    if (Bp != R) HIP_TRY(hipMemsetAsync(dp, 0, sizeof(float) * (size_t)D, stream));
-    if (Bn != R) HIP_TRY(hipMemsetAsync(dn, 0, sizeof(float) * (size_t)D, stream));
     bpr_backward_kernel<<<dim3((unsigned)((R + 3) / 4)), 256, 0, stream>>>(u, Bu, p, Bp, n, Bn, R, D, wd, batch_size, grad_out,
                                                                             du, dp, dn);
     LAUNCH_CHECK();
+    if (Bu != R || Bp != R || Bn != R) {                        // (only with R > 1: an operand of one row against several)
+        bpr_backward_bcast_kernel<<<1, 256, 0, stream>>>(u, Bu, p, Bp, n, Bn, R, D, wd, batch_size, grad_out, du, dp, dn);
+        LAUNCH_CHECK();
+    }
     return NGCF_OK;
 }
 

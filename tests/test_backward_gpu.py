@@ -165,6 +165,29 @@ def test_bpr_backward_matches_golden_grads(dev):
             np.testing.assert_allclose(t.grad.cpu().numpy(), want, atol=1e-7 + 1e-5 * np.abs(want).max(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("which", ["u", "p", "n", "pn"])
+def test_bpr_backward_of_a_broadcast_operand_is_a_sum_in_row_order(which, dev):
+    """A [1, D] operand against R rows (bprloss.py broadcasts like torch): its gradient is the sum of the per-row terms - formed by
+    one workgroup in row order (r04: no float atomic is left), so two runs are bit-identical and the values are torch autograd's
+    through the oracle's loss (R and D beyond one chunk / one column block: 700 rows, 300 columns)."""
+    pkg = _pkg()
+    R, D, wd, bs = 700, 300, 0.025, 64
+    gen = torch.Generator().manual_seed(5)
+    base = {k: torch.randn((1 if k in which else R, D), generator=gen) * 0.3 for k in "upn"}
+    got = []
+    for _ in range(2):
+        t = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        (2.0 * pkg.BPR(wd, bs)(t["u"], t["p"], t["n"])).backward()
+        got.append({k: v.grad.clone() for k, v in t.items()})
+    for k in "upn":
+        assert got[0][k].shape == base[k].shape and torch.equal(got[0][k], got[1][k])
+    t = {k: v.clone().double().requires_grad_(True) for k, v in base.items()}
+    (2.0 * orc.bpr_torch(t["u"], t["p"], t["n"], wd, bs)).backward()
+    for k in "upn":
+        want = t[k].grad.numpy()
+        np.testing.assert_allclose(got[0][k].cpu().numpy(), want, atol=1e-7 + 2e-5 * np.abs(want).max(), rtol=1e-4, err_msg=k)
+
+
 @pytest.mark.parametrize("n_rows,d_in,d_out,strided", [(0, 16, 8, False), (33, 7, 5, False), (1000, 65, 64, False),
                                                         (9001, 128, 128, False), (70000, 130 - 2, 96, True), (3000, 130, 200, False),
                                                         (777, 515, 64, True),
