@@ -109,8 +109,10 @@ class _TrainGraphs:
             pool = torch.cuda.graph_pool_handle()
             self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             al = self._aliases()
+            status_host = model._status_host_buf()
             with torch.cuda.graph(self.fwd, pool=pool):
                 outs = self._body(al)
+                status_host.copy_(model._status, non_blocking=True)    # last node: the status word where the host can see it
             self.outs = tuple(outs)
             self.all_E = model._all_E.detach()                         # the capture's all_E: what the module's attributes alias after a replay
             self.gouts = tuple(torch.empty_like(o) for o in outs)
@@ -122,14 +124,14 @@ class _TrainGraphs:
         # emb_ratio != 1: the injection blends (w <- w (1-r) + feats r) and is not idempotent - the three warm-up forwards must not
         # count, or the batch's user rows would be blended four times by the time of the first replay
         uw[self.idx[0].clamp(0, model.n_user - 1)] = rows_before
-        self._keep = (self.ws.buf, model._scratch, model._status, getattr(model, "_seed_state", None))
+        self._keep = (self.ws.buf, model._scratch, model._status, getattr(model, "_seed_state", None), model._status_host)
         self._baked = self._pointers()
         model._all_E = model.all_users_emb = model.all_items_emb = None     # (they alias the capture's all_E: set again by every replay)
         self._free = static_result_baseline(self.all_E)                      # ... which only this object and its autograd nodes hold now
 
     def _pointers(self):
         m = self.model
-        return tuple(None if t is None else t.data_ptr() for t in (self.ws.buf, m._scratch, m._status, getattr(m, "_seed_state", None)))
+        return tuple(None if t is None else t.data_ptr() for t in (self.ws.buf, m._scratch, m._status, getattr(m, "_seed_state", None), m._status_host))
 
     def intact(self) -> bool:
         """Every buffer whose address the two graphs bake in is still the tensor it was at capture."""
@@ -287,6 +289,7 @@ class NGCF(nn.Module):
         self._carry: List[Optional[torch.Tensor]] = [None, None]
         self._scratch: Optional[torch.Tensor] = None
         self._status: Optional[torch.Tensor] = None
+        self._status_host: Optional[torch.Tensor] = None
         self.check_indices = True        # raise IndexError on out-of-range ids (one host sync per forward)
         # where the random masks come from: "reference" = torch's default CPU generator, drawn exactly where the reference
         # draws (bit-identical masks for the same torch.manual_seed, one host round trip per layer); "device" = counter
@@ -338,6 +341,21 @@ class NGCF(nn.Module):
         if self._status is None or self._status.device != dev:
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
         return self._status
+
+    def _status_host_buf(self):
+        """Pinned host mirror of `_status`: the captured training forward copies the word there as its last node (r04), so
+        `_peek_status` sees an earlier replay's out-of-range id without a host sync."""
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._status_host
+
+    def _peek_status(self):
+        """Raise IndexError for an out-of-range id of any graph replay the GPU has finished - no host sync unless there is one."""
+        h = self._status_host
+        if h is not None and int(h[0]) != 0:
+            self.check_indices_now()
+        for g in list(self._graphs.values()):
+            g.peek_status()
 
     def _scratch_buf(self, dev):
         if self._scratch is None or self._scratch.device != dev or self._scratch.numel() != self.n_user:
@@ -640,8 +658,9 @@ class NGCF(nn.Module):
         """The inference forward as a hipGraph replay (graphed.GraphedForward): captured on first use per (index vector lengths,
         year slice), re-captured when a parameter or `lap_list` entry was replaced (`.to()`, a new tensor assigned); in-place
         updates (`load_state_dict`, optimizer steps) need nothing - the graph reads the parameters when it runs.  Returns fresh
-        tensors like the eager path.  Out-of-range ids raise IndexError at the latest `index_check_every` calls later (the status
-        word is sticky; `check_indices_now()` reads it on demand)."""
+        tensors like the eager path.  Out-of-range ids raise IndexError at the next call after the GPU has run the replay (its last
+        node copies the sticky status word to pinned host memory: `_peek_status`, no sync), at the latest `index_check_every` calls
+        later (a synchronising read); `check_indices_now()` reads it on demand."""
         from .graphed import GraphedForward
         year_idx = self._year_index(year)
         sizes = (len(u_id), len(pos_item), len(neg_item))
@@ -664,6 +683,8 @@ class NGCF(nn.Module):
         if self._static_result_held(g.out[0], g._free):
             return None                                                # a caller kept the last replay's all_*_emb: eager, into fresh tensors
         self._graph_calls += 1
+        if self.check_indices:
+            self._peek_status()                                        # an earlier replay's bad id, as soon as the GPU got there
         g.load_inputs(u_id=u_id, age=age, sex=sex, month=month, day=day, dow=dow, pos_item=pos_item,
                       neg_item=neg_item if sizes[2] > 0 else None)
         u, p, n = g.replay(check=False)
@@ -689,6 +710,8 @@ class NGCF(nn.Module):
             g.check_status()
         if self._train_graphs and self._status is not None and int(self._status.item()) != 0:
             self._status.zero_()
+            if self._status_host is not None:
+                self._status_host.zero_()
             raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
 
     def _train_graph_wanted(self, node_flag, u_id, pos_item, neg_item) -> bool:
@@ -788,6 +811,8 @@ class NGCF(nn.Module):
                 raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
         self._train_graphs[key] = g
         self._train_calls += 1
+        if self.check_indices:
+            self._peek_status()                                        # an earlier replay's bad id, as soon as the GPU got there
         with _eng._on(dev):
             outs = g(*args)
         if self.check_indices and self._train_calls % max(1, int(self.index_check_every)) == 0:

@@ -55,6 +55,9 @@ class GraphedForward:
             raise RuntimeError("GraphedForward: capturing the loss needs the negative items (with_neg=True)")
         self.criterion, self._loss_ws, self.loss = criterion, _eng.Workspace(), None
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # r04: a pinned host mirror of the status word, copied by the LAST node of the graph: the next call can see an earlier
+        # replay's out-of-range id without a host sync (`peek_status`), instead of up to `index_check_every` calls later
+        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.scratch = torch.full((model.n_user,), -1, dtype=torch.int32, device=dev)
         # the weights the injection overwrites must look the same at capture time as before it
         saved = model.user_embedding.weight.data[:1].clone()
@@ -73,9 +76,11 @@ class GraphedForward:
             self.out = self._body()
             if criterion is not None:
                 self.loss = self._loss(self.out)
+            self.status_host.copy_(self.status, non_blocking=True)
         torch.cuda.synchronize(dev)
         model.user_embedding.weight.data[:1].copy_(saved)  # row 0 was injected with the all-zero warm-up batch
         self.status.zero_()
+        self.status_host.zero_()
         self._baked = self._baked_pointers()
         self._free = static_result_baseline(self.out[0])     # what the static all_E reads when nobody but this object holds it
 
@@ -130,7 +135,7 @@ class GraphedForward:
     def _baked_pointers(self):
         b = self.bufs
         return tuple(t.data_ptr() for t in (b._ws.buf, b._carry[0], b._carry[1], self.scratch,
-                                            self.status, self._loss_ws.buf) if t is not None)
+                                            self.status, self.status_host, self._loss_ws.buf) if t is not None)
 
     def replay(self, check: bool = True):
         """Replay on whatever `self.inputs[...]` (the graph's static int64 index buffers) hold: callers that write their
@@ -149,9 +154,16 @@ class GraphedForward:
         return u, p, n
 
     def check_status(self):
-        if int(self.status.item()) != 0:
+        if int(self.status.item()) != 0:                   # (a host sync: every replay so far has written its mirror)
             self.status.zero_()
+            self.status_host.zero_()
             raise IndexError("index out of range in NGCF.forward (u_id / feature ids / pos_item / neg_item)")
+
+    def peek_status(self):
+        """No host sync: has a replay that the GPU has FINISHED seen an out-of-range id?  (Its last node copied the sticky status
+        word into pinned host memory.)  Then raise like `check_status`."""
+        if int(self.status_host[0]) != 0:
+            self.check_status()
 
 
 
@@ -196,8 +208,10 @@ class GraphedTrainStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
+            status_host = model._status_host_buf()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body()
+                status_host.copy_(self.status, non_blocking=True)     # last node: the status word where the host can see it
         finally:
             model._forced_year_idx = None
         torch.cuda.synchronize(dev)
@@ -215,7 +229,7 @@ class GraphedTrainStep:
 
     def _baked_pointers(self):
         m = self.model
-        return tuple(t.data_ptr() for t in ([m._ws.buf, self.criterion._ws.buf, getattr(m, "_seed_state", None), self.status] + list(m.parameters()))
+        return tuple(t.data_ptr() for t in ([m._ws.buf, self.criterion._ws.buf, getattr(m, "_seed_state", None), self.status, m._status_host] + list(m.parameters()))
                      if t is not None)
 
     def __call__(self, **batch):
@@ -234,11 +248,15 @@ class GraphedTrainStep:
                 self.inputs[k].copy_(v.reshape(-1), non_blocking=True)
         if self._baked_pointers() != self._baked:
             raise RuntimeError("GraphedTrainStep: a buffer or parameter baked into the captured step was replaced; capture again")
+        if self.model.check_indices:
+            self.model._peek_status()                        # an earlier step's out-of-range id, as soon as the GPU got there (no sync)
         self.graph.replay()
         self.steps_done += 1
         m = self.model
         m._e0_cache.invalidate()
         if m.check_indices and self.steps_done % max(1, int(m.index_check_every)) == 0 and int(self.status.item()) != 0:
             self.status.zero_()
+            if m._status_host is not None:
+                m._status_host.zero_()
             raise IndexError("index out of range in a graph-replayed training step (u_id / feature ids / pos_item / neg_item)")
         return self.loss

@@ -160,6 +160,17 @@ def test_unchanged_callers_get_the_graph_replay(dev):
             for _ in range(3):
                 auto(node_flag=False, **bad)
     auto.check_indices_now()                                           # the status word was reset by the raise
+    auto.index_check_every = 10 ** 9                                   # r04: no synchronising read at all - the pinned mirror reports it
+    good = eval_batch()
+    with torch.no_grad():
+        for _ in range(3):
+            auto(node_flag=False, **good)                              # (this shape replays)
+        auto(node_flag=False, **bad)                                   # no raise: nothing has read the word yet
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            auto(node_flag=False, **good)
+        auto(node_flag=False, **good)
+    auto.index_check_every = 2
     plain.user_embedding.weight.data.copy_(auto.user_embedding.weight.data)
     plain.invalidate_all_E()       # r04: a write through .data from outside bypasses the version counter the retained all_E watches
     same(eval_batch())
@@ -284,6 +295,16 @@ def test_unchanged_training_loops_get_graph_replays(dev):
         model(node_flag=True, **bad)
     u, p, n = model(node_flag=True, **batches[0])                      # and the model keeps working
     assert torch.isfinite(u).all()
+    # r04: without any synchronising read (index_check_every far away) the bad id of a replay is reported by the NEXT call that
+    # finds the GPU past it - the replay's last node copies the sticky status word into pinned host memory
+    model.index_check_every = 10 ** 9
+    del u, p, n                                                        # (a forward whose backward can still run keeps the next one eager)
+    model(node_flag=True, **bad)                                       # no raise here: nothing has read the word
+    torch.cuda.synchronize()                                           # (a training loop gets here through loss.item(), a log line, ...)
+    with pytest.raises(IndexError):
+        model(node_flag=True, **batches[0])
+    assert torch.isfinite(model(node_flag=True, **batches[0])[0]).all()
+    model.index_check_every = 1
     # eval-mode calls in between take the inference path and do not disturb the training graphs
     model.eval()
     with torch.no_grad():
