@@ -43,7 +43,7 @@ const char *ngcf_last_error(void);
 const char *ngcf_target_arch(void);
 /* ABI version of this header.  ngcf_version() returns the value the library was built with; the Python mirror refuses to bind
  * a library whose version differs (a stale .so would otherwise receive shifted arguments). */
-#define NGCF_ABI_VERSION 6
+#define NGCF_ABI_VERSION 7
 int ngcf_version(void);
 
 /* Tunables of the kernel dispatch (thresholds, lab switches).  The library reads its NGCF_* environment variables ONCE, in
@@ -226,6 +226,13 @@ int ngcf_copy_rows_indexed_f32(const float *src, int64_t lds, float *dst, int64_
  * kernel (checked against it by the caller once per process), several times faster (vector loops, no lock per element). */
 int ngcf_torch_cpu_bernoulli(uint8_t *rng_state, int64_t state_bytes, int64_t n, double keep, uint8_t *flags, float *noise,
                              float scale, int64_t *n_kept);
+
+/* The draws of a whole forward in ONE call (r04; a helper thread draws the next forward's masks ahead and must not need the
+ * interpreter between two draws): draw i is ngcf_torch_cpu_bernoulli(n[i], keep[i], flags[i], noise[i], scale[i]) -> n_kept[i], one
+ * after the other on the same state bytes; n[i] = -1 stands for "as many as the latest earlier draw WITH flags kept" (the node
+ * mask of a layer has one flag per entry the earlier layers kept, NGCF.py:126: its buffer must hold the first such draw's n). */
+int ngcf_torch_cpu_bernoulli_seq(uint8_t *rng_state, int64_t state_bytes, int n_draws, const int64_t *n, const double *keep,
+                                 uint8_t *const *flags, float *const *noise, const float *scale, int64_t *n_kept);
 
 /* ---- feature injection (NGCF.py:103-115) ---------------------------------------------- */
 /*

@@ -195,32 +195,180 @@ def _host_rng_ok() -> bool:
     return _HOST_RNG["ok"]
 
 
-def _reference_bernoulli(n: int, p_drop: float, noise_shape=None):
+def _bernoulli_from_state(st: torch.Tensor, n: int, keep: float, noise_shape=None):
+    """n draws of Bernoulli(keep) from the mt19937 state bytes `st` (a `torch.get_rng_state()` tensor, advanced in place) through
+    `ngcf_torch_cpu_bernoulli`: (keep flags uint8[n] or None, kept count, noise float32 `noise_shape` or None).  Touches neither
+    torch's generator nor the GPU (ctypes releases the GIL for the call): safe on a helper thread."""
+    import ctypes as C
+    flags = None if noise_shape is not None else torch.empty(n, dtype=torch.uint8)
+    noise = torch.empty(noise_shape, dtype=torch.float32) if noise_shape is not None else None
+    scale = float(torch.ones(1, dtype=torch.float32).div_(keep)) if noise is not None else 0.0
+    kept = C.c_int64()
+    _eng._lib.check(_eng._lib.load().ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), n, keep, None if flags is None else flags.data_ptr(),
+                                                              None if noise is None else noise.data_ptr(), scale, C.byref(kept)))
+    return flags, int(kept.value), noise
+
+
+def _reference_bernoulli(n: int, p_drop: float, noise_shape=None, state: Optional[torch.Tensor] = None):
     """`nn.Dropout(p_drop)` in training mode on a CPU tensor of n ones, drawn from torch's DEFAULT CPU generator exactly as the
     reference draws it (NGCF.py:93-100 on float64 ones, NGCF.py:142 on the float32 activations; both take one 64-bit draw per
     element): returns (keep flags uint8[n] or None, kept count, noise float32 `noise_shape` or None) - the flags for the node
-    dropout, the noise tensor (0 or 1/(1-p) as torch rounds it) for the message dropout."""
-    import ctypes as C
+    dropout, the noise tensor (0 or 1/(1-p) as torch rounds it) for the message dropout.  `state`: draw from these state bytes
+    (advanced in place) instead of the default generator (`_DrawAhead`; needs `_host_rng_ok()`)."""
     keep = 1.0 - float(p_drop)
     if keep >= 1.0 or keep <= 0.0:        # torch's dropout returns its input (p = 0) or zeros (p = 1) WITHOUT touching the generator
         kept_all = keep >= 1.0
         if noise_shape is not None:
             return None, -1, torch.full(noise_shape, 1.0 if kept_all else 0.0, dtype=torch.float32)
         return torch.full((n,), 1 if kept_all else 0, dtype=torch.uint8), n if kept_all else 0, None
+    if state is not None:
+        return _bernoulli_from_state(state, n, keep, noise_shape)
     if _host_rng_ok():
         st = torch.get_rng_state()
-        flags = None if noise_shape is not None else torch.empty(n, dtype=torch.uint8)
-        noise = torch.empty(noise_shape, dtype=torch.float32) if noise_shape is not None else None
-        scale = float(torch.ones(1, dtype=torch.float32).div_(keep)) if noise is not None else 0.0
-        kept = C.c_int64()
-        _eng._lib.check(_eng._lib.load().ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), n, keep, None if flags is None else flags.data_ptr(),
-                                                                  None if noise is None else noise.data_ptr(), scale, C.byref(kept)))
+        out = _bernoulli_from_state(st, n, keep, noise_shape)
         torch.set_rng_state(st)
-        return flags, int(kept.value), noise
+        return out
     if noise_shape is not None:
         return None, -1, torch.nn.functional.dropout(torch.ones(noise_shape, dtype=torch.float32), p=p_drop, training=True)
     flags = torch.nn.functional.dropout(torch.ones(n, dtype=torch.float64), p=p_drop, training=True).type(torch.bool)
     return flags, int(flags.sum()), None
+
+
+def _draw_program(program, state: Optional[torch.Tensor] = None):
+    """The draws of ONE forward in the reference's order (NGCF.py:123-142), as a generator of (keep flags, kept count, noise) per
+    layer.  `program` = (stored entries of L, node-dropout p or None, message-dropout p per layer or None, N, widths): the node
+    mask of layer k has one flag per entry the earlier layers kept (cumulative, NGCF.py:126), so the sizes follow from the draws
+    themselves - nothing here depends on the batch or on the GPU."""
+    nnz, p_node, drops, N, widths = program
+    n = nnz
+    for k in range(len(widths) - 1):
+        flags = kept = noise = None
+        if p_node is not None:
+            flags, kept, _ = _reference_bernoulli(n, p_node, None, state)
+            n = kept
+        if drops is not None and drops[k] > 0:
+            noise = _reference_bernoulli(N * widths[k + 1], drops[k], (N, widths[k + 1]), state)[2]
+        yield flags, kept, noise
+
+
+class _DrawAhead:
+    """r04: the NEXT forward's reference-mode masks, drawn on a helper thread while this step's launches, backward and optimizer run.
+    The masks of a forward are a function of the generator state alone (`_draw_program`), so when a forward ends the helper starts
+    from a COPY of the state the forward left behind and runs the same program again; the next forward takes the result only if the
+    default generator is still in exactly that state (nobody seeded it or drew from it in between) and the program is the same
+    (same year slice, same dropout rates, same mode) - it then installs the state the helper ended in, as if it had drawn itself.
+    Anything else: the result is dropped and the masks are drawn in place.  Bit-identical either way.  Off: NGCF_DRAW_AHEAD=0."""
+
+    MAX_BYTES = 64 << 20                   # (flags + noise of one forward: 7 MB at the Seoul shape; not for C3-sized masks)
+
+    def __init__(self):
+        self.thread, self.job = None, None
+        self.hits = self.misses = 0
+        # the helper writes into PINNED buffers (two sets, used in turn: the masks of one forward may still be on their way to the
+        # device - asynchronous copies out of page-locked memory - while the helper already draws the next ones into the other set)
+        self.sets = [{}, {}]                # per set: {"program", "buffers", "event"}
+        self.turn = 0
+
+    def __reduce__(self):                  # copy.deepcopy(model), torch.save(model): a copy starts without a helper
+        return (_DrawAhead, ())
+
+    @staticmethod
+    def wanted(program) -> bool:
+        nnz, p_node, drops, N, widths = program
+        size = (3 * nnz if p_node is not None else 0) + (4 * N * sum(widths[1:]) if drops is not None else 0)
+        return os.environ.get("NGCF_DRAW_AHEAD", "1") != "0" and size <= _DrawAhead.MAX_BYTES and _host_rng_ok()
+
+    def start(self, program):
+        import threading
+        if not self.wanted(program):
+            self.thread = self.job = None
+            return
+        import ctypes as C
+        # every buffer is allocated HERE and the helper makes ONE foreign call for the whole forward (ngcf_torch_cpu_bernoulli_seq):
+        # between two calls it would have to wait for the interpreter lock, which the launching thread gives up every 5 ms at worst
+        nnz, p_node, drops, N, widths = program
+        node_keep = None if p_node is None else 1.0 - p_node
+        if node_keep is not None and not 0.0 < node_keep < 1.0:          # p = 0 / p = 1: torch draws nothing; not worth a helper
+            self.thread = self.job = None
+            return
+        self.turn ^= 1
+        bset = self.sets[self.turn]
+        if bset.get("program") != program:                               # (page-locked allocations are slow: once per program and set)
+            pin = torch.cuda.is_available()
+            bset.clear()
+            bset.update(program=program, event=None,
+                        flags=[torch.empty(nnz, dtype=torch.uint8, pin_memory=pin) for _ in widths[1:]] if node_keep is not None else None,
+                        noise=[torch.empty((N, w), dtype=torch.float32, pin_memory=pin) if drops is not None and drops[k] > 0 else None
+                               for k, w in enumerate(widths[1:])])
+        elif bset["event"] is not None:
+            bset["event"].synchronize()                                  # the copies that read this set two forwards ago (long done)
+        draws, slots = [], []                # draws: (n or -1, keep, flags, noise, scale) as the C routine takes them; slots: per layer
+        for k in range(len(widths) - 1):
+            fl = nz = i_fl = None
+            if node_keep is not None:
+                fl = bset["flags"][k]                                    # (a layer keeps at most what layer 0 started from)
+                i_fl = len(draws)
+                draws.append((nnz if k == 0 else -1, node_keep, fl, None, 0.0))     # -1: as many as the previous layer kept
+            if drops is not None and drops[k] > 0:
+                pk = 1.0 - drops[k]
+                nz = bset["noise"][k]
+                if 0.0 < pk < 1.0:
+                    draws.append((N * widths[k + 1], pk, None, nz, float(torch.ones(1, dtype=torch.float32).div_(pk))))
+                else:
+                    nz.fill_(1.0 if pk >= 1.0 else 0.0)
+            slots.append((fl, i_fl, nz))
+        m = len(draws)
+        job = {"program": program, "start": torch.get_rng_state(), "end": None, "rc": None}
+        st = job["start"].clone()
+        c_n, c_keep = (C.c_int64 * m)(*[d[0] for d in draws]), (C.c_double * m)(*[d[1] for d in draws])
+        c_flags = (C.c_void_p * m)(*[None if d[2] is None else d[2].data_ptr() for d in draws])
+        c_noise = (C.c_void_p * m)(*[None if d[3] is None else d[3].data_ptr() for d in draws])
+        c_scale, c_kept = (C.c_float * m)(*[d[4] for d in draws]), (C.c_int64 * m)()
+        fn = _eng._lib.load().ngcf_torch_cpu_bernoulli_seq
+        st_ptr, st_len = st.data_ptr(), st.numel()
+
+        def work():
+            job["rc"] = fn(st_ptr, st_len, m, c_n, c_keep, c_flags, c_noise, c_scale, c_kept)     # (the GIL is released for the call)
+
+        def finish():                        # on the taking thread: (flags cut to what was drawn, kept count, noise) per layer
+            if job["rc"] != 0:
+                return None
+            out, n_flags = [], nnz
+            for fl, i_fl, nz in slots:
+                kept = None
+                if fl is not None:
+                    fl, kept = fl[:n_flags], int(c_kept[i_fl])
+                    n_flags = kept
+                out.append((fl, kept, nz))
+            job["end"] = st
+            return out
+        job["finish"] = finish
+        self.job = job
+        self.thread = threading.Thread(target=work, name="ngcf-draw-ahead", daemon=True)
+        self.thread.start()
+
+    def copied(self):
+        """The forward has queued its copies of the masks it took: the set they live in is free once the stream got past them."""
+        bset = self.sets[self.turn]
+        if torch.cuda.is_available() and bset.get("program") is not None:
+            if bset["event"] is None:
+                bset["event"] = torch.cuda.Event()
+            bset["event"].record()
+
+    def take(self, program):
+        """The helper's masks for `program` if they are the ones this forward would draw now, else None."""
+        job, thread = self.job, self.thread
+        self.job = self.thread = None
+        if job is None:
+            return None
+        thread.join()
+        result = job["finish"]() if job["program"] == program and torch.equal(job["start"], torch.get_rng_state()) else None
+        if result is None:
+            self.misses += 1
+            return None
+        torch.set_rng_state(job["end"])
+        self.hits += 1
+        return result
 
 
 def _spmm_mode() -> int:
@@ -460,21 +608,26 @@ class NGCF(nn.Module):
 
     def _reference_draws_body(self, year_idx, node_ref, drop, mess_ref, src, dev, N, widths):
         csrs, flags, masks = [], [], []
-        for k in range(self.n_layer):
+        program = (src.nnz if node_ref else 0, float(self.node_dropout) if node_ref else None,
+                   tuple(float(x) for x in drop) if mess_ref else None, N, tuple(widths))
+        ahead = self.__dict__.get("_draw_ahead")
+        if ahead is None:
+            ahead = self.__dict__["_draw_ahead"] = _DrawAhead()
+        draws = ahead.take(program)                          # drawn by the helper thread during the previous step, or None
+        ahead_hit = draws is not None                        # (then the masks sit in page-locked buffers: asynchronous copies)
+        for k, (keep, n_kept, noise) in enumerate(draws if ahead_hit else _draw_program(program)):
             if node_ref:
                 # one flag per entry of the matrix as the previous layers left it (cumulative, NGCF.py:126); the thinned CSR is a
                 # device compaction of the previous one into buffers this module keeps from step to step (ngcf_csr_filter)
-                keep, n_kept, _ = _reference_bernoulli(src.nnz, self.node_dropout)
-                keep = keep.to(dev)
+                keep = keep.to(dev, non_blocking=ahead_hit)
                 src = src.filtered(keep, None, n_kept, reuse=self._filt.pop(("L", year_idx, k), None))
                 self._filt[("L", year_idx, k)] = src
                 csrs.append(src)
                 flags.append(keep)
-            if mess_ref and drop[k] > 0:
-                _, _, noise = _reference_bernoulli(N * widths[k + 1], drop[k], (N, widths[k + 1]))
-                masks.append(noise.to(dev, non_blocking=False))
-            else:
-                masks.append(None)
+            masks.append(noise.to(dev, non_blocking=ahead_hit) if noise is not None else None)
+        if ahead_hit:
+            ahead.copied()
+        ahead.start(program)                                 # the next forward's masks, from the state this one leaves behind
         # the thinned matrices are not symmetric: their transposes are built only if a backward needs them
         return (csrs if node_ref else None, (lambda: self._thinned_transposes(year_idx, csrs, flags)) if node_ref else None,
                 masks if mess_ref else None)

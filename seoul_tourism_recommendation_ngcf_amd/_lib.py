@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be loaded before libngcf_hip.so, see module do
 from . import _build
 
 OK, ERR_ARG, ERR_HIP, ERR_INDEX, ERR_WORKSPACE = 0, 1, 2, 3, 4
-ABI_VERSION = 6          # NGCF_ABI_VERSION of include/ngcf_hip.h these prototypes were written against
+ABI_VERSION = 7          # NGCF_ABI_VERSION of include/ngcf_hip.h these prototypes were written against
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
 
@@ -98,6 +98,8 @@ PROTOTYPES = {
     "ngcf_p2p_fence": (C.c_int, [_vp, _vp]),
     "ngcf_p2p_join": (C.c_int, [_vp, _vp]),
     "ngcf_torch_cpu_bernoulli": (C.c_int, [_vp, _i64, _i64, C.c_double, _vp, _vp, _f32, C.POINTER(_i64)]),
+    "ngcf_torch_cpu_bernoulli_seq": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_vp), C.POINTER(_vp),
+                                               C.POINTER(_f32), C.POINTER(_i64)]),
     "ngcf_p2p_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64), C.c_int]),
     "ngcf_sum_slots_f32": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp]),
 }

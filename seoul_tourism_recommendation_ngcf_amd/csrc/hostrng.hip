@@ -128,3 +128,21 @@ extern "C" __attribute__((target_clones("avx512f", "avx2", "default"))) int ngcf
     if (n_kept) *n_kept = kept;
     return NGCF_OK;
 }
+
+// the draws of one forward, one after the other on the same state bytes (include/ngcf_hip.h): one call, so that a helper thread
+// holds no interpreter lock from the first draw to the last
+extern "C" int ngcf_torch_cpu_bernoulli_seq(uint8_t *rng_state, int64_t state_bytes, int n_draws, const int64_t *n, const double *keep,
+                                            uint8_t *const *flags, float *const *noise, const float *scale, int64_t *n_kept)
+{
+    if (n_draws < 0 || (n_draws > 0 && (!n || !keep || !flags || !noise || !scale || !n_kept)))
+        return fail(NGCF_ERR_ARG, "torch_cpu_bernoulli_seq: bad argument");
+    int64_t last_kept = -1;
+    for (int i = 0; i < n_draws; ++i) {
+        const int64_t ni = n[i] >= 0 ? n[i] : last_kept;
+        if (ni < 0) return fail(NGCF_ERR_ARG, "torch_cpu_bernoulli_seq: draw %d refers to an earlier draw with flags, there is none", i);
+        const int rc = ngcf_torch_cpu_bernoulli(rng_state, state_bytes, ni, keep[i], flags[i], noise[i], scale[i], &n_kept[i]);
+        if (rc != NGCF_OK) return rc;
+        if (flags[i]) last_kept = n_kept[i];
+    }
+    return NGCF_OK;
+}

@@ -75,3 +75,55 @@ def test_bad_state_is_refused():
     assert lib.ngcf_torch_cpu_bernoulli(st.data_ptr(), 100, 5, 0.5, None, None, 0.0, None) != 0        # too short for the layout
     st[8:12] = 0                                                                                      # left = 0: not a state torch produces
     assert lib.ngcf_torch_cpu_bernoulli(st.data_ptr(), st.numel(), 5, 0.5, None, None, 0.0, None) != 0
+
+
+def test_draw_ahead_hands_over_exactly_what_the_forward_would_draw():
+    """r04: `_DrawAhead` draws the next forward's reference-mode masks on a helper thread from a copy of the generator state.  The
+    result is taken only if the default generator is still in that state and the program (entries of L, rates, widths) is the same;
+    then flags, kept counts, noise tensors and the generator state afterwards are what drawing in place gives - and after a
+    reseed, a foreign draw or another program the helper's work is dropped."""
+    import copy
+    import importlib
+    mod = importlib.import_module("seoul_tourism_recommendation_ngcf_amd.NGCF")
+    if not mod._host_rng_ok():
+        pytest.skip("this torch build draws differently: masks come from torch itself, nothing is drawn ahead")
+    program = (9001, 0.3, (0.1, 0.0, 0.25), 321, (10, 8, 6, 7))       # node dropout + message dropout on two of three layers
+
+    def in_place(seed):
+        torch.manual_seed(seed)
+        return list(mod._draw_program(program)), torch.get_rng_state()
+
+    def same(a, b):
+        for (f1, k1, n1), (f2, k2, n2) in zip(a, b):
+            assert k1 == k2 and torch.equal(f1, f2) and ((n1 is None and n2 is None) or torch.equal(n1, n2))
+
+    want, state_after = in_place(5)
+    assert want[1][2] is None and want[0][2].shape == (321, 8) and want[1][0].numel() == want[0][1]   # p = 0: no draw; cumulative sizes
+    ahead = mod._DrawAhead()
+    torch.manual_seed(5)
+    ahead.start(program)
+    got = ahead.take(program)
+    assert got is not None and ahead.hits == 1
+    same(got, want)
+    assert torch.equal(torch.get_rng_state(), state_after)
+    # the generator moved on in between (a reseed; a foreign draw): dropped, the forward draws in place
+    torch.manual_seed(5)
+    ahead.start(program)
+    torch.manual_seed(6)
+    assert ahead.take(program) is None and ahead.misses == 1
+    torch.manual_seed(5)
+    ahead.start(program)
+    torch.rand(1)
+    before = torch.get_rng_state()
+    assert ahead.take(program) is None and torch.equal(torch.get_rng_state(), before)
+    # another program (the other year slice, eval mode from epoch 2 on): dropped
+    torch.manual_seed(5)
+    ahead.start(program)
+    assert ahead.take((9001, 0.3, None, 321, (10, 8, 6, 7))) is None
+    assert ahead.take(program) is None                                  # nothing in flight
+    # masks the size of C3's are not drawn ahead; a copied module starts without a helper
+    assert not mod._DrawAhead.wanted((100_000_000, 0.1, None, 1_100_000, (128, 128, 128, 128)))
+    torch.manual_seed(5)
+    ahead.start(program)
+    assert copy.deepcopy(ahead).job is None
+    assert ahead.take(program) is not None

@@ -98,6 +98,38 @@ def test_the_references_own_loop_is_bit_identical_with_and_without_graph_replays
         assert len(m._train_graphs) == 0                                # host-drawn masks: nothing to capture, and nothing captured
 
 
+def test_reference_mode_masks_drawn_ahead_are_the_masks_drawn_in_place(lap, dev, monkeypatch):
+    """r04: in the module's DEFAULT dropout modes the masks of the next forward are drawn on a helper thread while the step runs
+    (`NGCF._DrawAhead`: from a copy of the generator state, taken over only if the generator is still in that state).  The
+    reference's loop gives the same losses and the same final parameters with the helper on and off - through the mode switch at
+    the end of epoch 1 (another program: message dropout off), the evaluation batches in between (no draws) and a re-seed in the
+    middle of an epoch - and the helper's masks are the ones used wherever the program repeats."""
+    pkg = _pkg()
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("NGCF_DRAW_AHEAD", on)
+        model, trace, modes, sd = _experiment(pkg, lap, dev, "reference", False)
+        ahead = model.__dict__.get("_draw_ahead")
+        out.append((trace, sd, (ahead.hits, ahead.misses) if ahead is not None else (0, 0)))
+        # a re-seed between two steps is honoured: what the helper drew from the old state is dropped
+        torch.manual_seed(99)
+        b = _batch(torch.Generator().manual_seed(1), B, dev)
+        u1 = model(node_flag=True, **b)[0].detach().clone()
+        model(node_flag=True, **b)
+        torch.manual_seed(99)
+        assert torch.equal(model(node_flag=True, **b)[0].detach(), u1)
+        out[-1] += (torch.get_rng_state().clone(),)
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert torch.equal(out[0][3], out[1][3])                            # the default generator ends in the same state
+    assert out[0][2] == (0, 0)
+    hits, misses = out[1][2]
+    # 12 training forwards: the first has nothing to take, the first eval-mode one meets another program; within an epoch the year
+    # slice, the rates and the mode repeat - the short last batch draws the same masks' sizes (they do not depend on the batch)
+    assert hits >= 9 and misses <= 2, (hits, misses)
+
+
 def test_injection_with_a_blending_ratio_is_applied_once_per_step_under_graph_replays(lap, dev):
     """emb_ratio = 0.5: the capture's warm-up forwards must not blend the batch's user rows."""
     pkg = _pkg()
