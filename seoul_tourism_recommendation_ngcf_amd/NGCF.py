@@ -344,7 +344,8 @@ class _DrawAhead:
             return out
         job["finish"] = finish
         self.job = job
-        self.thread = threading.Thread(target=work, name="ngcf-draw-ahead", daemon=True)
+        # (not a daemon: the interpreter waits for it at exit - a millisecond at most - instead of freeing the buffers under it)
+        self.thread = threading.Thread(target=work, name="ngcf-draw-ahead", daemon=False)
         self.thread.start()
 
     def copied(self):
