@@ -266,8 +266,10 @@ class _DrawAhead:
         self.hits = self.misses = 0
         # the helper writes into PINNED buffers (two sets, used in turn: the masks of one forward may still be on their way to the
         # device - asynchronous copies out of page-locked memory - while the helper already draws the next ones into the other set)
-        self.sets = [{}, {}]                # per set: {"program", "buffers", "event"}
+        self.sets = [{}, {}]                # per set: {"program", "flags", "noise", "event"}
         self.turn = 0
+        self.spare = {}                     # (program, set index) -> a set put aside when another program came (year slices alternate)
+        self.miss_streak = self.pause = 0   # three misses in a row (batches whose programs do not repeat): no helper for 32 forwards
 
     def __reduce__(self):                  # copy.deepcopy(model), torch.save(model): a copy starts without a helper
         return (_DrawAhead, ())
@@ -291,11 +293,19 @@ class _DrawAhead:
         if node_keep is not None and not 0.0 < node_keep < 1.0:          # p = 0 / p = 1: torch draws nothing; not worth a helper
             self.thread = self.job = None
             return
+        if self.pause > 0:                                               # the programs of this caller's batches do not repeat: stand back
+            self.pause -= 1
+            self.thread = self.job = None
+            return
         self.turn ^= 1
         bset = self.sets[self.turn]
         if bset.get("program") != program:                               # (page-locked allocations are slow: once per program and set)
-            pin = torch.cuda.is_available()
+            if bset.get("program") is not None and len(self.spare) < 6:
+                self.spare[(bset["program"], self.turn)] = dict(bset)    # another year slice / mode: its buffers wait for its return
             bset.clear()
+            bset.update(self.spare.pop((program, self.turn), {}))
+        if bset.get("program") != program:
+            pin = torch.cuda.is_available()
             bset.update(program=program, event=None,
                         flags=[torch.empty(nnz, dtype=torch.uint8, pin_memory=pin) for _ in widths[1:]] if node_keep is not None else None,
                         noise=[torch.empty((N, w), dtype=torch.float32, pin_memory=pin) if drops is not None and drops[k] > 0 else None
@@ -366,9 +376,13 @@ class _DrawAhead:
         result = job["finish"]() if job["program"] == program and torch.equal(job["start"], torch.get_rng_state()) else None
         if result is None:
             self.misses += 1
+            self.miss_streak += 1
+            if self.miss_streak >= 3:
+                self.miss_streak, self.pause = 0, 32
             return None
         torch.set_rng_state(job["end"])
         self.hits += 1
+        self.miss_streak = 0
         return result
 
 

@@ -123,7 +123,50 @@ def test_draw_ahead_hands_over_exactly_what_the_forward_would_draw():
     assert ahead.take(program) is None                                  # nothing in flight
     # masks the size of C3's are not drawn ahead; a copied module starts without a helper
     assert not mod._DrawAhead.wanted((100_000_000, 0.1, None, 1_100_000, (128, 128, 128, 128)))
+    assert ahead.misses == 3 and ahead.pause == 32                      # three misses in a row: it stands back (next test)
+    ahead = mod._DrawAhead()
     torch.manual_seed(5)
     ahead.start(program)
     assert copy.deepcopy(ahead).job is None
     assert ahead.take(program) is not None
+
+
+def test_draw_ahead_with_programs_that_do_not_repeat():
+    """Year slices (or modes) that alternate from batch to batch: the helper's guess - the same program again - is wrong every time.
+    Its buffers are put aside per program and come back (no page-locked allocation per forward), and after three misses in a row
+    it stands back for 32 forwards; a hit resets the count."""
+    import importlib
+    mod = importlib.import_module("seoul_tourism_recommendation_ngcf_amd.NGCF")
+    if not mod._host_rng_ok():
+        pytest.skip("this torch build draws differently: nothing is drawn ahead")
+    A = (5000, 0.3, (0.1,), 100, (8, 8))
+    B = (7000, 0.3, (0.1,), 100, (8, 8))
+    ahead = mod._DrawAhead()
+    torch.manual_seed(1)
+    seen = {}
+    for i in range(3):                                                  # A is guessed, B comes (and the other way round): three misses
+        guess, comes = (A, B) if i % 2 == 0 else (B, A)
+        ahead.start(guess)
+        key = (guess, ahead.turn)
+        ptr = ahead.sets[ahead.turn]["flags"][0].data_ptr()
+        assert seen.setdefault(key, ptr) == ptr
+        assert ahead.take(comes) is None
+    assert ahead.misses == 3 and ahead.pause == 32
+    for _ in range(32):
+        ahead.start(A)
+        assert ahead.job is None and ahead.take(A) is None              # standing back: nothing in flight, nothing counted
+    assert ahead.misses == 3 and ahead.pause == 0
+    ahead.start(A)
+    assert ahead.take(A) is not None and ahead.hits == 1 and ahead.miss_streak == 0
+    # the buffers of a program that went away and came back are the ones it had (same set index)
+    ahead.turn = 1
+    ahead.start(A)
+    a_ptr = ahead.sets[0]["flags"][0].data_ptr()
+    ahead.take(A)
+    ahead.turn = 1
+    ahead.start(B)
+    ahead.take(B)
+    ahead.turn = 1
+    ahead.start(A)
+    assert ahead.sets[0]["flags"][0].data_ptr() == a_ptr
+    ahead.take(A)
