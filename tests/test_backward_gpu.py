@@ -380,7 +380,7 @@ def test_row_sparse_transposed_product_vs_dense(d, heavy, drop, dev):
     assert float((again - want).abs().max()) <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("d,n_item,drop", [(128, 20000, 0.0), (130, 600, 0.3), (65, 20000, 0.3)])
+@pytest.mark.parametrize("d,n_item,drop", [(128, 20000, 0.0), (130, 600, 0.3), (65, 20000, 0.3), (600, 600, 0.0)])   # 600: two 512-column panels
 def test_row_sparse_transposed_product_with_the_bitmap_in_lds_is_bit_identical(d, n_item, drop, dev, lib_options):
     """r04: on a large matrix (>= 2^22 stored entries, N <= 1.13 M) `ngcf_spmm_t_rows_f32` runs `spmm_t_rows_bm_kernel`: 16 consecutive
     rows per wave, the membership of an entry's column in the R rows tested on a bitmap in LDS, hits parked and replayed in entry
