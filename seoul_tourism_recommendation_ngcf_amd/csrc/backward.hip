@@ -137,44 +137,59 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__re
     }
     // four chains over the segment (positions j0 + 4 i + q; the last (j1 - j0) % 4 positions go to chain 0), combined as
     // (s0 + s1) + (s2 + s3): a fixed order.  r04: the positions `order[j]` of 64 entries are fetched by ONE load (a lane each) and
-    // handed round with readlane, and a lane keeps the sums of up to eight column blocks - the loads of the gradient rows then
-    // depend on nothing but that one load (before: order -> row -> next order, twice per group of four, for every column block:
-    // a popular item is gathered 40 times in a batch of 1 024 on the Seoul graph's 100 items - 22 us for a 3 072-row batch).
+    // handed round with readlane, a lane keeps the sums of five column blocks and sixteen gradient rows are requested before the
+    // first is added - the loads depend on nothing but that one load (before: order -> row -> next order, twice per group of four,
+    // for every column block: a popular item is gathered 40 times in a batch of 1 024 on the Seoul graph's 100 items - 22 us).
     const int lane = threadIdx.x & 63;
     const int64_t n4 = (j1 - j0) / 4 * 4;                           // entries in full groups of four
-    for (int c0 = 0; c0 < d; c0 += 512) {
-        float s[8][4];
+    constexpr int kQ = 5;                                           // column blocks of 64 per pass (the Seoul model's 260 columns: one pass)
+    for (int c0 = 0; c0 < d; c0 += 64 * kQ) {
+        float s[kQ][4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s[q][0] = s[q][1] = s[q][2] = s[q][3] = 0.f;
+        for (int q = 0; q < kQ; ++q) s[q][0] = s[q][1] = s[q][2] = s[q][3] = 0.f;
         for (int64_t jb = j0; jb < j1; jb += 64) {                  // (jb - j0 is a multiple of 64: groups of four never straddle)
             const int cnt = (int)(j1 - jb < 64 ? j1 - jb : 64);
             const long long ord = order[jb + (lane < cnt ? lane : 0)];
             const int lo = (int)(ord & 0xffffffffll), hi = (int)(ord >> 32);
-            const auto pos = [&](int t) {
-                return ((long long)__builtin_amdgcn_readlane(hi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, t);
+            const auto row_of = [&](int t) {
+                return g + (((long long)__builtin_amdgcn_readlane(hi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, t)) * ldg + c0 + lane;
             };
             int t = 0;
-            for (; t + 4 <= cnt && jb - j0 + t + 4 <= n4; t += 4) {
-                const float *g0 = g + pos(t) * ldg + c0 + lane, *g1 = g + pos(t + 1) * ldg + c0 + lane;
-                const float *g2 = g + pos(t + 2) * ldg + c0 + lane, *g3 = g + pos(t + 3) * ldg + c0 + lane;
+            for (; t + 16 <= cnt && jb - j0 + t + 16 <= n4; t += 16) {     // four groups at once: sixteen rows in flight, added in group order
+                float v[16][kQ];
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (c0 + lane + 64 * q < d) {
-                        s[q][0] += g0[64 * q];
-                        s[q][1] += g1[64 * q];
-                        s[q][2] += g2[64 * q];
-                        s[q][3] += g3[64 * q];
-                    }
+                for (int u = 0; u < 16; ++u) {
+                    const float *gp = row_of(t + u);
+#pragma unroll
+                    for (int q = 0; q < kQ; ++q) v[u][q] = c0 + lane + 64 * q < d ? gp[64 * q] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int q = 0; q < kQ; ++q) s[q][u & 3] += v[u][q];
+            }
+            for (; t + 4 <= cnt && jb - j0 + t + 4 <= n4; t += 4) {
+                float v[4][kQ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *gp = row_of(t + u);
+#pragma unroll
+                    for (int q = 0; q < kQ; ++q) v[u][q] = c0 + lane + 64 * q < d ? gp[64 * q] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < kQ; ++q) s[q][u] += v[u][q];
             }
             for (; t < cnt; ++t) {
-                const float *g0 = g + pos(t) * ldg + c0 + lane;
+                const float *gp = row_of(t);
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (c0 + lane + 64 * q < d) s[q][0] += g0[64 * q];
+                for (int q = 0; q < kQ; ++q)
+                    if (c0 + lane + 64 * q < d) s[q][0] += gp[64 * q];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < kQ; ++q)
             if (c0 + lane + 64 * q < d) out[r * ldo + c0 + lane + 64 * q] = (s[q][0] + s[q][1]) + (s[q][2] + s[q][3]);
     }
 }
