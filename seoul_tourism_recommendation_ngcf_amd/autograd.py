@@ -30,6 +30,11 @@ def _padded_rows(n: int, d: int, dev) -> torch.Tensor:
     return torch.empty((n, (d + 31) // 32 * 32), dtype=torch.float32, device=dev)[:, :d]
 
 
+def _final_rows(n: int, d: int, dev) -> torch.Tensor:
+    """[n, d] fp32, contiguous: the gradient of the two embedding tables as autograd wants it (see Propagate.backward)."""
+    return torch.empty((n, d), dtype=torch.float32, device=dev)
+
+
 def _alloc_all_E(N: int, widths, dev) -> torch.Tensor:
     """all_E [N, D] for the `cat` of NGCF.py:147.  The reference forces embed_size to a multiple of 5 (NGCF.py:39-43: 65, 130,
     515), so D is usually not a multiple of 4 and contiguous rows would not be 16-byte aligned.  Then the rows are padded to a
@@ -353,7 +358,7 @@ class Propagate(torch.autograd.Function):
                 gw1[k], gb1[k], gw2[k], gb2[k] = _bwd_weight(dM, LE_c, E_c, ws)
                 dLE_c, dE_c = _bwd_input(dM, w1[k], w2[k], LE_c, E_c, ws)
                 N = int(all_E.shape[0])
-                dE = _padded_rows(N, d_in, all_E.device)
+                dE = _final_rows(N, d_in, all_E.device) if k == 0 else _padded_rows(N, d_in, all_E.device)
                 slot = torch.full((N,), -1, dtype=torch.int32, device=all_E.device)
                 slot[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=all_E.device)
                 ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1])
@@ -370,7 +375,16 @@ class Propagate(torch.autograd.Function):
             dLE, dE = _bwd_input(dM, w1[k], w2[k], LE_k, E_k, ws)                 # one MFMA kernel at any width, dS/dP never stored
             del dM
             ed = None if ctx.edge_drops is None else (ctx.edge_drops[k][0], ctx.edge_drops[k][1], True)
-            _add_rows(dE, _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed))     # dE += (thinned L)^T . dLE
+            S = _eng.spmm(ctx.csrs_t[k], dLE, ws=ws, edge_drop=ed)                # (thinned L)^T . dLE
+            if k == 0 and dE.stride(0) != d_in:
+                # The gradient of the embedding tables leaves as the row blocks dE0[:U], dE0[U:].  At a width that is not a multiple
+                # of 32 (65, 130, 515: the reference's own) dE is a view of padded rows, and autograd's AccumulateGrad CLONES a
+                # gradient that is not laid out like its parameter (r04 trace: 0.24 ms per step at C3, two copy kernels per step at
+                # the Seoul shape); the last sum is therefore written into a contiguous matrix, whose row blocks it takes as they are.
+                dE = torch.add(dE, S, out=_final_rows(int(dE.shape[0]), d_in, dE.device))
+            else:
+                _add_rows(dE, S)                                                  # dE += ...
+            del S
             dC = dE
         dE0 = dC
         if rows is not None:
