@@ -747,6 +747,11 @@ def main():
                             "peak": L2_PEAK_GBS, "unit": "GB/s",
                             "frac": (gather_bytes / (mean_ms * 1e-3) / 1e9 / L2_PEAK_GBS) if mean_ms > 0 else 0.0,
                             "gather_bytes_per_launch": gather_bytes,
+                            # r04: the same ceiling as a request rate - one 128-byte line request per (entry, line): 16.8-18.8 TB/s
+                            # of gathered rows = 131-147 G requests/s (TCC_HIT + TCC_MISS of a launch: profiles/r04_c3_pmc_summary.txt)
+                            "line_requests_per_launch": gather_bytes / 128,
+                            "achieved_G_lines_per_s": gather_bytes / 128 / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0,
+                            "ceiling_G_lines_per_s": [131, 147],
                             "note": "explanatory, not the headline: roofline.frac stays SURVEY 8d model A"},
             "loss": float(loss),
         }
